@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the PM step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of deposit -> Poisson solve -> gradient -> gather + kick + drift over the
+whole particle set, with all state resident in HBM before the timed region starts.  At N=1 the
+workload is the headline configuration: a two-galaxy collision of 16,777,216 particles on a
+512^3 mesh.  Prints ONE JSON line (rank 0).
+
+The metric is particle-updates per second.  `roofline` prices the dominant stage against the
+8 TB/s HBM peak using the algorithmic bytes of that stage (one read and one write of each
+operand per stage: deposit 16N+4M, forward FFT 24M, inverse FFT 24M, gradient 16M,
+gather+kick+drift 48N+12M; whole step 64N+80M).  `cpu_baseline` is the CPU oracle (single
+thread, as the reference ships) timed on one step of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "nbody-simulation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0
+BOX = 10000
+DT = 0.005
+
+
+def plummer_blob(rng, n, scale, rmax):
+    """Plummer sphere positions (density ~ (1 + r^2/a^2)^-5/2), truncated at rmax."""
+    out = np.empty((n, 3), np.float32)
+    done = 0
+    while done < n:
+        m = int((n - done) * 1.1) + 16
+        u = rng.random(m)
+        r = scale / np.sqrt(u ** (-2.0 / 3.0) - 1.0)
+        r = r[r < rmax][: n - done]
+        k = len(r)
+        d = rng.normal(size=(k, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        out[done:done + k] = (d * r[:, None]).astype(np.float32)
+        done += k
+    return out
+
+
+def make_workload(name, n, L, seed):
+    """Synthetic particle sets (float32 positions, velocities, masses)."""
+    rng = np.random.default_rng(seed)
+    if name == "uniform":
+        pos = (rng.random((n, 3)) * L).astype(np.float32)
+        vel = rng.normal(0, 10, (n, 3)).astype(np.float32)
+        return pos, vel, np.ones(n, np.float32)
+    if name == "two_galaxy":
+        # two Plummer blobs (scale radii 0.02 L and 0.05 L) placed +-0.1 L apart along (0.67, 0.33, 0)
+        # about the box centre, relative velocity (-3000, 300, 0) split for zero total momentum
+        n1 = n // 2
+        n2 = n - n1
+        d = np.array([0.67, 0.33, 0.0])
+        d /= np.linalg.norm(d)
+        c = 0.5 * L
+        p1 = plummer_blob(rng, n1, 0.02 * L, 0.45 * L) + (c - 0.1 * L * d).astype(np.float32)
+        p2 = plummer_blob(rng, n2, 0.05 * L, 0.45 * L) + (c + 0.1 * L * d).astype(np.float32)
+        vrel = np.array([-3000.0, 300.0, 0.0])
+        v1 = rng.normal(0, 10, (n1, 3)) - 0.5 * vrel
+        v2 = rng.normal(0, 10, (n2, 3)) + 0.5 * vrel
+        pos = np.vstack((p1, p2)).astype(np.float32)
+        pos %= np.float32(L)
+        vel = np.vstack((v1, v2)).astype(np.float32)
+        return pos, vel, np.ones(n, np.float32)
+    if name == "disk":
+        # exponential disk rho ~ exp(-R/Rd) exp(-|z|/z0), Rd = 0.03 L, z0 = 0.003 L, equal masses
+        R = rng.gamma(2.0, 0.03 * L, n)
+        phi = rng.uniform(0, 2 * np.pi, n)
+        z = rng.laplace(0.0, 0.003 * L, n)
+        pos = np.stack((0.5 * L + R * np.cos(phi), 0.5 * L + R * np.sin(phi), 0.5 * L + z), axis=1)
+        pos = (pos % L).astype(np.float32)
+        vel = rng.normal(0, 10, (n, 3)).astype(np.float32)
+        return pos, vel, np.ones(n, np.float32)
+    raise ValueError(name)
+
+
+def stage_bytes(n, m):
+    return {"bin": 0, "deposit": 16 * n + 4 * m, "fft_fwd": 24 * m, "green": 0, "fft_inv": 24 * m,
+            "gradient": 16 * m, "gather": 48 * n + 12 * m}
+
+
+def cpu_baseline(pos, vel, mass, G, L, dt):
+    """One step of the CPU oracle on the same workload, single thread."""
+    from oracle import pm_oracle as O
+    O.build()
+    O.cell_keys(pos[:1000], G, L)                 # load the library outside the timed region
+    t0 = time.perf_counter()
+    O.pm_step(pos, vel, mass, G, L, dt)
+    dt_s = time.perf_counter() - t0
+    return {"value": len(pos) / dt_s, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "sample": f"1 full PM step of the same workload (N={len(pos)}, G={G}) in {dt_s:.1f} s: C loops for "
+                      "deposit/gather, numpy/scipy.fft (1 worker) for Poisson/gradient/integrator",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="two_galaxy", choices=["two_galaxy", "uniform", "disk"])
+    ap.add_argument("--n", type=int, default=16_777_216)
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--no-fused-gradient", action="store_true")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run for --gpus > 1")
+
+    import pm                                     # loads libpm.so (raises if it is missing)
+    pm.load()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist          # rendezvous and barriers only
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    n, G, L = args.n, args.grid, BOX
+    m = G ** 3
+    # every rank holds an independent replica of the workload (its own seed): until the mesh is
+    # slab-decomposed across ranks, multi-GPU runs are N replicas
+    pos, vel, mass = make_workload(args.workload, n, L, 1052 + rank)
+    fused = not args.no_fused_gradient
+    sim = pm.Simulation(G, L, pos, vel, mass, device=local_rank, fused_gradient=fused)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        sim.synchronize()
+
+    sim.step(DT, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    sim.step(DT, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    # per-stage durations: HIP events on the engine's stream, same steps again
+    sim.set_flags(timing=True, fused_gradient=fused)
+    sim.step(DT, args.steps)
+    stages = sim.stage_times()
+    sim.set_flags(timing=False, fused_gradient=fused)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        b = stage_bytes(n, m)
+        per = {s: (ms / c if c else 0.0) for s, (ms, c) in stages.items()}
+        dom = max((s for s in per if b[s] > 0), key=lambda s: per[s])
+        ach = b[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+        b_step = 64 * n + 80 * m
+        out = {
+            "metric": "particle-updates/sec per PM step (N=16M, 512^3 mesh)",
+            "value": world * n * args.steps / elapsed, "unit": "particle-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "fused_gradient": fused,
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b[dom], "ms_per_launch": per[dom]},
+            "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved": b_step / (ms_step * 1e-3) / 1e9,
+                              "unit": "GB/s", "frac": b_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "stage_ms": per,
+        }
+        if args.cpu_baseline == "auto" and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pos, vel, mass, G, L, DT)
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+/*
+ * pm.h -- C ABI of libpm.so, the MI355X (gfx950) Particle-Mesh force engine.
+ *
+ * This is the drop-in boundary for the force/integration path of
+ * MappaCrappa/Nbody-Simulation.  Each entry point names the reference
+ * interface it replaces (file:line under the reference's root).  All
+ * functions are extern "C", take plain pointers and sizes, return 0 on
+ * success or a PM_E* code, and leave a message for pm_last_error().
+ *
+ * Ownership and threading: a context owns every device allocation, its HIP
+ * stream and its FFT plans; the caller owns every host buffer.  One context
+ * = one GPU = one host thread at a time (calls on one context must not
+ * overlap; different contexts are independent).  Host buffers are read or
+ * written synchronously: when a pm_set_* / pm_get_* call returns, the copy is
+ * done.  The compute calls (pm_deposit ... pm_step) are asynchronous on the
+ * context's stream; pm_synchronize() waits for them.
+ *
+ * Mesh arrays are C-order (G,G,G) float32, index [i][j][k] <-> (x,y,z), k
+ * fastest (functions.py:22,61).  Particle arrays on the host are AoS (N,3).
+ */
+#ifndef PM_H
+#define PM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pm_ctx pm_ctx;
+
+/* error codes */
+enum { PM_OK = 0, PM_EINVAL = 1, PM_ENOMEM = 2, PM_EHIP = 3, PM_EFFT = 4, PM_ESTATE = 5 };
+
+/* host dtypes of particle arrays */
+enum { PM_F32 = 0, PM_F64 = 1 };
+
+/* meshes addressable by pm_get_mesh / pm_set_mesh */
+enum { PM_MESH_DENSITY = 0, PM_MESH_POTENTIAL = 1, PM_MESH_GX = 2, PM_MESH_GY = 3, PM_MESH_GZ = 4 };
+
+/* pm_create flags */
+enum {
+    PM_FLAG_TIMING = 1u,      /* record HIP events around every stage (pm_stage_times) */
+    PM_FLAG_FUSED_GRADIENT = 2u /* pm_step differences the potential inside the gather instead of writing gx,gy,gz */
+};
+
+/* stages reported by pm_stage_times, in this order */
+enum { PM_STAGE_BIN = 0, PM_STAGE_DEPOSIT = 1, PM_STAGE_FFT_FWD = 2, PM_STAGE_GREEN = 3, PM_STAGE_FFT_INV = 4,
+       PM_STAGE_GRADIENT = 5, PM_STAGE_GATHER = 6, PM_NSTAGES = 7 };
+
+/* Replaces the module constants grid_size / box_size (main.py:5-6) and the
+ * per-call allocations of every reference function.  n_capacity is the
+ * largest particle count the context will hold.  Returns NULL on failure
+ * (pm_last_error(NULL) then describes why). */
+pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags);
+void pm_destroy(pm_ctx *ctx);
+
+/* Replaces the bare arrays positions / velocities / masses created at
+ * main.py:25-33.  pos and vel are host AoS (n,3) of dtype PM_F32 or PM_F64
+ * (the shipped default run has float64 velocities throughout and float64
+ * positions until the first drift, main.py:33,58-60); vel may be NULL
+ * (zeros), mass may be NULL (ones). */
+int pm_set_particles(pm_ctx *ctx, const void *pos, int pos_dtype, const void *vel, int vel_dtype,
+                     const float *mass, int64_t n);
+
+/* density_func(positions, grid_size, box_size, masses), the CIC branch:
+ * functions.py:19-70, call site main.py:50. */
+int pm_deposit(pm_ctx *ctx);
+/* compute_potential(density, grid_size): functions.py:73-89, call site main.py:51. */
+int pm_potential(pm_ctx *ctx);
+/* np.gradient(potential): call site main.py:54. */
+int pm_gradient(pm_ctx *ctx);
+/* force_func(potential_gradient, positions, grid_size, box_size), the CIC
+ * branch: functions.py:99-180, call site main.py:55.  Result via pm_get_forces. */
+int pm_forces(pm_ctx *ctx);
+/* force_CIC fused with the in-line kick / drift / wrap of main.py:58-60. */
+int pm_gather_kick_drift(pm_ctx *ctx, double dt);
+/* nsteps passes of the loop body main.py:50-60 with all state resident. */
+int pm_step(pm_ctx *ctx, double dt, int nsteps);
+
+/* Particle state in the caller's original order.  pos is written as float32
+ * (n,3) once a drift has happened, in the dtype given to pm_set_particles
+ * before; *pos_dtype / *vel_dtype report what was written. */
+int pm_get_particles(pm_ctx *ctx, void *pos, int *pos_dtype, void *vel, int *vel_dtype);
+int pm_get_forces(pm_ctx *ctx, float *forces /* (n,3) */);
+int pm_get_mesh(pm_ctx *ctx, int which, float *out /* G*G*G */);
+/* Upload a mesh, so that one stage can be run on the caller's input
+ * (granular mode: compute_potential(density), np.gradient(potential),
+ * force_CIC(gradient, ...) each take arrays the caller made). */
+int pm_set_mesh(pm_ctx *ctx, int which, const float *in /* G*G*G */);
+
+/* Cell order of the last binning: keys[r] = (i*G+j)*G+k of the r-th particle
+ * in cell order (cell (i,j,k) as functions.py:27-39 computes it), perm[r] =
+ * its index in the caller's original order.  Ties keep storage order. */
+int pm_get_cell_keys(pm_ctx *ctx, int64_t *keys, int64_t *perm);
+
+/* Accumulated milliseconds and call counts per stage since the last call
+ * (needs PM_FLAG_TIMING); both arrays have PM_NSTAGES entries.  Synchronises. */
+int pm_stage_times(pm_ctx *ctx, float *ms, int *calls);
+
+/* Replace the flags given to pm_create (e.g. switch stage timing on for a profiling pass). */
+int pm_set_flags(pm_ctx *ctx, unsigned flags);
+
+int pm_synchronize(pm_ctx *ctx);
+int64_t pm_num_particles(const pm_ctx *ctx);
+const char *pm_last_error(const pm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PM_H */

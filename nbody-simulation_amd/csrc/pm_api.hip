@@ -1,0 +1,442 @@
+// C ABI of libpm.so: context management, host copies, stage sequencing.
+#include "pm_internal.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+thread_local std::string g_create_error;
+std::once_flag g_fft_once;
+
+int fail(pm_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail((c), e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+#define FFT_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        rocfft_status s_ = (expr);                                                           \
+        if (s_ != rocfft_status_success)                                                     \
+            return fail((c), PM_EFFT, std::string(#expr) + ": rocfft status " + std::to_string((int)s_)); \
+    } while (0)
+
+template <typename T>
+int dalloc(pm_ctx *c, T **p, size_t count)
+{
+    if (*p) return PM_OK;
+    HIP_TRY(c, hipMalloc((void **)p, count * sizeof(T) + 16));
+    return PM_OK;
+}
+
+#define TRY(expr) do { int r_ = (expr); if (r_ != PM_OK) return r_; } while (0)
+
+struct stage_timer {
+    pm_ctx *c; int s; bool on;
+    stage_timer(pm_ctx *c_, int s_) : c(c_), s(s_), on((c_->flags & PM_FLAG_TIMING) != 0)
+    {
+        if (!on) return;
+        if (c->ev_used[s]) flush(c, s);
+        hipEventRecord(c->ev[s][0], c->stream);
+    }
+    ~stage_timer()
+    {
+        if (!on) return;
+        hipEventRecord(c->ev[s][1], c->stream);
+        c->ev_used[s] = true;
+    }
+    // One event pair per stage: the previous interval is read before the pair is reused.
+    static void flush(pm_ctx *c, int s)
+    {
+        if (!c->ev_used[s]) return;
+        float ms = 0.0f;
+        hipEventSynchronize(c->ev[s][1]);
+        if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) { c->ms[s] += ms; c->calls[s] += 1; }
+        c->ev_used[s] = false;
+    }
+};
+
+int bits_for(int64_t M)
+{
+    int b = 1;
+    while (((int64_t)1 << b) < M) ++b;
+    return b;
+}
+
+int alloc_particles(pm_ctx *c)
+{
+    size_t cap = (size_t)c->cap;
+    for (int u = 0; u < 2; ++u) {
+        for (int d = 0; d < 3; ++d) {
+            TRY(dalloc(c, &c->x[u][d], cap));
+            if (c->pos_in_f64) TRY(dalloc(c, &c->xd[u][d], cap));
+            if (c->vel_f64) TRY(dalloc(c, &c->vd[u][d], cap)); else TRY(dalloc(c, &c->vf[u][d], cap));
+        }
+        TRY(dalloc(c, &c->m[u], cap));
+        TRY(dalloc(c, &c->id[u], cap));
+    }
+    return PM_OK;
+}
+
+int ensure_binned(pm_ctx *c)
+{
+    if (c->binned) return PM_OK;
+    stage_timer t(c, PM_STAGE_BIN);
+    HIP_TRY(c, pm_launch_cell_keys(c));
+    HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
+    HIP_TRY(c, pm_launch_reorder(c));
+    HIP_TRY(c, pm_launch_cell_start(c));
+    c->binned = true;
+    return PM_OK;
+}
+
+int need_particles(pm_ctx *c)
+{
+    if (!c) return PM_EINVAL;
+    if (!c->m[0]) return fail(c, PM_ESTATE, "no particles: call pm_set_particles first");
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pm_last_error(const pm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int64_t pm_num_particles(const pm_ctx *ctx) { return ctx ? ctx->n : -1; }
+
+void pm_destroy(pm_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int u = 0; u < 2; ++u) {
+        for (int d = 0; d < 3; ++d) { hipFree(c->x[u][d]); hipFree(c->xd[u][d]); hipFree(c->vf[u][d]); hipFree(c->vd[u][d]); }
+        hipFree(c->m[u]); hipFree(c->id[u]);
+    }
+    hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
+    hipFree(c->cell_start); hipFree(c->gap_list); hipFree(c->gap_count);
+    hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum);
+    for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
+    hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage);
+    if (c->info) rocfft_execution_info_destroy(c->info);
+    if (c->fwd) rocfft_plan_destroy(c->fwd);
+    if (c->inv) rocfft_plan_destroy(c->inv);
+    for (int s = 0; s < PM_NSTAGES; ++s)
+        for (int k = 0; k < 2; ++k)
+            if (c->ev[s][k]) hipEventDestroy(c->ev[s][k]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(pm_ctx *c)
+{
+    const int G = c->g.G;
+    const size_t M = (size_t)c->g.M, cap = (size_t)c->cap;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int s = 0; s < PM_NSTAGES; ++s)
+        for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
+
+    TRY(dalloc(c, &c->key_in, cap));
+    TRY(dalloc(c, &c->key_out, cap));
+    TRY(dalloc(c, &c->src, cap));
+    c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
+    HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
+    TRY(dalloc(c, &c->cell_start, M + 1));
+    c->gap_cap = (uint32_t)(M / 65536 + 2);
+    TRY(dalloc(c, &c->gap_list, 3 * (size_t)c->gap_cap));
+    TRY(dalloc(c, &c->gap_count, 1));
+    TRY(dalloc(c, &c->density, M));
+    TRY(dalloc(c, &c->potential, M));
+    for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
+    TRY(dalloc(c, &c->spectrum, (size_t)G * G * c->g.Gh));
+    TRY(dalloc(c, &c->forces, 3 * cap));
+    HIP_TRY(c, hipMalloc(&c->stage, cap * 3 * sizeof(double) + 16));
+
+    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    const size_t lengths[3] = {(size_t)G, (size_t)G, (size_t)G};
+    FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  rocfft_precision_single, 3, lengths, 1, nullptr));
+    FFT_TRY(c, rocfft_plan_create(&c->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  rocfft_precision_single, 3, lengths, 1, nullptr));
+    size_t wf = 0, wi = 0;
+    FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->fwd, &wf));
+    FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->inv, &wi));
+    c->fft_work_bytes = wf > wi ? wf : wi;
+    FFT_TRY(c, rocfft_execution_info_create(&c->info));
+    if (c->fft_work_bytes) {
+        HIP_TRY(c, hipMalloc(&c->fft_work, c->fft_work_bytes));
+        FFT_TRY(c, rocfft_execution_info_set_work_buffer(c->info, c->fft_work, c->fft_work_bytes));
+    }
+    FFT_TRY(c, rocfft_execution_info_set_stream(c->info, c->stream));
+    return PM_OK;
+}
+
+pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags)
+{
+    if (grid_size < 2 || grid_size > 1625) { fail(nullptr, PM_EINVAL, "grid_size must be in [2, 1625] (cell keys are 32-bit)"); return nullptr; }
+    if (!(box_size > 0.0) || !std::isfinite(box_size)) { fail(nullptr, PM_EINVAL, "box_size must be positive and finite"); return nullptr; }
+    if (n_capacity < 0 || n_capacity >= ((int64_t)1 << 32) - 1) { fail(nullptr, PM_EINVAL, "n_capacity must be in [0, 2^32-2]"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        fail(nullptr, PM_EHIP, "no such HIP device: " + std::to_string(device) + " of " + std::to_string(ndev));
+        return nullptr;
+    }
+    pm_ctx *c = new pm_ctx;
+    c->g.G = grid_size; c->g.Gh = grid_size / 2 + 1;
+    c->g.M = (int64_t)grid_size * grid_size * grid_size;
+    c->g.L = box_size; c->g.inv = (double)grid_size / box_size; c->g.Lf = (float)box_size;
+    c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
+    if (create_impl(c) != PM_OK) {
+        g_create_error = c->err;
+        pm_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+int pm_synchronize(pm_ctx *c)
+{
+    if (!c) return PM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel, int vel_dtype, const float *mass, int64_t n)
+{
+    if (!c) return PM_EINVAL;
+    if (n < 0 || n > c->cap) return fail(c, PM_EINVAL, "n outside [0, n_capacity]");
+    if (!pos && n > 0) return fail(c, PM_EINVAL, "pos is NULL");
+    if ((pos_dtype != PM_F32 && pos_dtype != PM_F64) || (vel_dtype != PM_F32 && vel_dtype != PM_F64))
+        return fail(c, PM_EINVAL, "dtype must be PM_F32 or PM_F64");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pos_in_f64 = c->pos_f64 = (pos_dtype == PM_F64);
+    c->vel_f64 = (vel_dtype == PM_F64);
+    TRY(alloc_particles(c));
+    c->n = n; c->cur = 0; c->binned = false; c->have_forces = false;
+    const int u = 0;
+    size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
+    if (n > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->stage, pos, (size_t)n * 3 * ps, hipMemcpyHostToDevice, c->stream));
+        void *dst[3];
+        for (int d = 0; d < 3; ++d) dst[d] = c->pos_f64 ? (void *)c->xd[u][d] : (void *)c->x[u][d];
+        HIP_TRY(c, pm_launch_aos_to_soa(c, c->stage, c->pos_f64, dst, n));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (vel) {
+            HIP_TRY(c, hipMemcpyAsync(c->stage, vel, (size_t)n * 3 * vs, hipMemcpyHostToDevice, c->stream));
+            for (int d = 0; d < 3; ++d) dst[d] = c->vel_f64 ? (void *)c->vd[u][d] : (void *)c->vf[u][d];
+            HIP_TRY(c, pm_launch_aos_to_soa(c, c->stage, c->vel_f64, dst, n));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (mass) HIP_TRY(c, hipMemcpyAsync(c->m[u], mass, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, pm_launch_fill_particles_defaults(c, vel == nullptr, mass == nullptr));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PM_OK;
+}
+
+int pm_deposit(pm_ctx *c)
+{
+    TRY(need_particles(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure_binned(c));
+    stage_timer t(c, PM_STAGE_DEPOSIT);
+    HIP_TRY(c, pm_launch_deposit(c));
+    return PM_OK;
+}
+
+int pm_potential(pm_ctx *c)
+{
+    if (!c) return PM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        stage_timer t(c, PM_STAGE_FFT_FWD);
+        void *in[1] = {c->density}, *out[1] = {c->spectrum};
+        FFT_TRY(c, rocfft_execute(c->fwd, in, out, c->info));
+    }
+    {
+        stage_timer t(c, PM_STAGE_GREEN);
+        HIP_TRY(c, pm_launch_green(c));
+    }
+    {
+        stage_timer t(c, PM_STAGE_FFT_INV);
+        void *in[1] = {c->spectrum}, *out[1] = {c->potential};
+        FFT_TRY(c, rocfft_execute(c->inv, in, out, c->info));
+    }
+    return PM_OK;
+}
+
+int pm_gradient(pm_ctx *c)
+{
+    if (!c) return PM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    stage_timer t(c, PM_STAGE_GRADIENT);
+    HIP_TRY(c, pm_launch_gradient(c));
+    return PM_OK;
+}
+
+int pm_forces(pm_ctx *c)
+{
+    TRY(need_particles(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    stage_timer t(c, PM_STAGE_GATHER);
+    HIP_TRY(c, pm_launch_gather(c, 0.0, false, true, false));
+    c->have_forces = true;
+    return PM_OK;
+}
+
+static int gather_kick_drift(pm_ctx *c, double dt, bool fused)
+{
+    stage_timer t(c, PM_STAGE_GATHER);
+    HIP_TRY(c, pm_launch_gather(c, dt, true, false, fused));
+    c->pos_f64 = false;      // positions are float32 from the first drift on (main.py:60)
+    c->binned = false;
+    c->have_forces = false;
+    return PM_OK;
+}
+
+int pm_gather_kick_drift(pm_ctx *c, double dt)
+{
+    TRY(need_particles(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    return gather_kick_drift(c, dt, false);
+}
+
+int pm_step(pm_ctx *c, double dt, int nsteps)
+{
+    TRY(need_particles(c));
+    if (nsteps < 0) return fail(c, PM_EINVAL, "nsteps < 0");
+    const bool fused = (c->flags & PM_FLAG_FUSED_GRADIENT) != 0;
+    for (int s = 0; s < nsteps; ++s) {
+        TRY(pm_deposit(c));
+        TRY(pm_potential(c));
+        if (!fused) TRY(pm_gradient(c));
+        TRY(gather_kick_drift(c, dt, fused));
+    }
+    return PM_OK;
+}
+
+int pm_get_particles(pm_ctx *c, void *pos, int *pos_dtype, void *vel, int *vel_dtype)
+{
+    TRY(need_particles(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n;
+    if (pos_dtype) *pos_dtype = c->pos_f64 ? PM_F64 : PM_F32;
+    if (vel_dtype) *vel_dtype = c->vel_f64 ? PM_F64 : PM_F32;
+    if (pos && n) {
+        HIP_TRY(c, pm_launch_export_particles(c, c->stage, c->pos_f64, nullptr));
+        HIP_TRY(c, hipMemcpyAsync(pos, c->stage, n * 3 * (c->pos_f64 ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (vel && n) {
+        HIP_TRY(c, pm_launch_export_particles(c, nullptr, false, c->stage));
+        HIP_TRY(c, hipMemcpyAsync(vel, c->stage, n * 3 * (c->vel_f64 ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PM_OK;
+}
+
+int pm_get_forces(pm_ctx *c, float *forces)
+{
+    TRY(need_particles(c));
+    if (!c->have_forces) return fail(c, PM_ESTATE, "no forces: call pm_forces first");
+    if (!forces) return fail(c, PM_EINVAL, "forces is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n) {
+        HIP_TRY(c, pm_launch_export_forces(c, (float *)c->stage));
+        HIP_TRY(c, hipMemcpyAsync(forces, c->stage, (size_t)c->n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PM_OK;
+}
+
+static float *mesh_ptr(pm_ctx *c, int which)
+{
+    switch (which) {
+    case PM_MESH_DENSITY: return c->density;
+    case PM_MESH_POTENTIAL: return c->potential;
+    case PM_MESH_GX: return c->grad[0];
+    case PM_MESH_GY: return c->grad[1];
+    case PM_MESH_GZ: return c->grad[2];
+    default: return nullptr;
+    }
+}
+
+int pm_get_mesh(pm_ctx *c, int which, float *out)
+{
+    if (!c) return PM_EINVAL;
+    float *p = mesh_ptr(c, which);
+    if (!p || !out) return fail(c, PM_EINVAL, "bad mesh selector or NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, p, (size_t)c->g.M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+int pm_set_mesh(pm_ctx *c, int which, const float *in)
+{
+    if (!c) return PM_EINVAL;
+    float *p = mesh_ptr(c, which);
+    if (!p || !in) return fail(c, PM_EINVAL, "bad mesh selector or NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(p, in, (size_t)c->g.M * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+int pm_get_cell_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
+{
+    TRY(need_particles(c));
+    if (!keys || !perm) return fail(c, PM_EINVAL, "NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure_binned(c));
+    if (c->n) {
+        // both exports fit the staging buffer: 2 * n * 8 <= cap * 24 bytes
+        int64_t *dk = (int64_t *)c->stage, *dp = dk + c->n;
+        HIP_TRY(c, pm_launch_export_keys(c, dk, dp));
+        HIP_TRY(c, hipMemcpyAsync(keys, dk, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(perm, dp, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PM_OK;
+}
+
+int pm_set_flags(pm_ctx *c, unsigned flags)
+{
+    if (!c) return PM_EINVAL;
+    if (flags & ~(unsigned)(PM_FLAG_TIMING | PM_FLAG_FUSED_GRADIENT)) return fail(c, PM_EINVAL, "unknown flag bits");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < PM_NSTAGES; ++s) stage_timer::flush(c, s);
+    c->flags = flags;
+    return PM_OK;
+}
+
+int pm_stage_times(pm_ctx *c, float *ms, int *calls)
+{
+    if (!c) return PM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < PM_NSTAGES; ++s) {
+        stage_timer::flush(c, s);
+        if (ms) ms[s] = c->ms[s];
+        if (calls) calls[s] = c->calls[s];
+        c->ms[s] = 0.0f; c->calls[s] = 0;
+    }
+    return PM_OK;
+}
+
+}  // extern "C"

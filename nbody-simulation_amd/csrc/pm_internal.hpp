@@ -1,0 +1,89 @@
+// Internal declarations shared by the translation units of libpm.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "pm.h"
+
+// Geometry handed to every kernel by value.
+struct pm_geom {
+    int G;          // cells per side
+    int Gh;         // G/2 + 1: length of the half-spectrum's fastest axis
+    int64_t M;      // G^3
+    double L;       // box size
+    double inv;     // G / L, the float64 quotient of functions.py:23
+    float Lf;       // (float)L for the float32 remainder of main.py:60
+};
+
+struct pm_ctx {
+    pm_geom g{};
+    int device = 0;
+    unsigned flags = 0;
+    int64_t cap = 0;    // particle capacity
+    int64_t n = 0;      // particles held
+    hipStream_t stream = nullptr;
+
+    // Particle state, SoA, double-buffered: `cur` is the live set, 1-cur the
+    // target of the next reorder.  Positions are float32 except between
+    // pm_set_particles(PM_F64) and the first drift, when xd[] holds them.
+    int cur = 0;
+    float *x[2][3] = {};
+    double *xd[2][3] = {};
+    float *vf[2][3] = {};
+    double *vd[2][3] = {};
+    float *m[2] = {};
+    uint32_t *id[2] = {};
+    bool pos_f64 = false;       // live positions are in xd[]
+    bool pos_in_f64 = false;    // dtype given to pm_set_particles
+    bool vel_f64 = false;
+    bool binned = false;        // live set is in cell order and cell_start matches it
+    bool have_forces = false;
+
+    // binning scratch
+    uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint32_t *cell_start = nullptr;     // M + 1 entries
+    uint32_t *gap_list = nullptr;       // big-gap records (lo, hi, value)
+    uint32_t *gap_count = nullptr;
+    uint32_t gap_cap = 0;
+
+    // meshes
+    float *density = nullptr, *potential = nullptr, *grad[3] = {};
+    float2 *spectrum = nullptr;
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *fft_work = nullptr;
+    size_t fft_work_bytes = 0;
+
+    float *forces = nullptr;            // (n,3) AoS in storage order
+    void *stage = nullptr;              // AoS staging for host copies, cap*3*8 bytes
+
+    hipEvent_t ev[PM_NSTAGES][2] = {};
+    bool ev_used[PM_NSTAGES] = {};
+    float ms[PM_NSTAGES] = {};
+    int calls[PM_NSTAGES] = {};
+
+    std::string err;
+};
+
+// ---- launchers (each enqueues on ctx->stream and returns a hipError_t) ----------------------
+hipError_t pm_launch_aos_to_soa(pm_ctx *c, const void *aos, bool f64, void *const dst[3], int64_t n);
+hipError_t pm_launch_fill_particles_defaults(pm_ctx *c, bool zero_vel, bool ones_mass);
+hipError_t pm_launch_cell_keys(pm_ctx *c);
+hipError_t pm_sort_pairs(pm_ctx *c, int bits);
+size_t pm_sort_tmp_bytes(int64_t cap);
+hipError_t pm_launch_reorder(pm_ctx *c);
+hipError_t pm_launch_cell_start(pm_ctx *c);
+hipError_t pm_launch_deposit(pm_ctx *c);
+hipError_t pm_launch_green(pm_ctx *c);
+hipError_t pm_launch_gradient(pm_ctx *c);
+hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);
+hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, bool pos_f64, void *vel_aos);
+hipError_t pm_launch_export_forces(pm_ctx *c, float *aos);
+hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm);

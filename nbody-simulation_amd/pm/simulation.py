@@ -1,0 +1,138 @@
+"""Resident-state PM engine: the step loop of the reference (main.py:44-67) with all state on
+the GPU.  Thin object layer over the C ABI of libpm.so."""
+import numpy as np
+
+from . import _lib as L
+
+
+class Simulation:
+    """grid_size / box_size / dt are the module constants of main.py:5-7; positions, velocities
+    and masses are the bare arrays of main.py:25-33, in their dtypes (float32 or float64)."""
+
+    def __init__(self, grid_size, box_size, positions=None, velocities=None, masses=None,
+                 interpolation="CIC", capacity=None, device=0, timing=False, fused_gradient=False):
+        if interpolation != "CIC":
+            raise NotImplementedError("only the CIC branch (main.py:9 default) runs on the GPU path")
+        self.lib = L.load()
+        self.grid_size, self.box_size = int(grid_size), box_size
+        n = 0 if positions is None else len(positions)
+        self.capacity = int(capacity if capacity is not None else max(n, 1))
+        flags = (L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
+        self.ctx = self.lib.pm_create(self.grid_size, float(box_size), self.capacity, int(device), flags)
+        if not self.ctx:
+            raise L.PMError("pm_create failed: " + self.lib.pm_last_error(None).decode())
+        self._vel_dtype = np.float32
+        if positions is not None:
+            self.set_particles(positions, velocities, masses)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.pm_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        L.check(self.ctx, rc)
+
+    @property
+    def n(self):
+        return int(self.lib.pm_num_particles(self.ctx))
+
+    def set_particles(self, positions, velocities=None, masses=None):
+        x = L.as_particle_array(positions, "positions")
+        v = None if velocities is None else L.as_particle_array(velocities, "velocities")
+        m = None if masses is None else np.ascontiguousarray(masses, dtype=np.float32)
+        if v is not None and len(v) != len(x) or m is not None and len(m) != len(x):
+            raise ValueError("positions, velocities and masses differ in length")
+        self._vel_dtype = np.float32 if v is None else v.dtype
+        self._ck(self.lib.pm_set_particles(self.ctx, L.ptr(x), L.PM_F64 if x.dtype == np.float64 else L.PM_F32,
+                                           L.ptr(v), L.PM_F64 if self._vel_dtype == np.float64 else L.PM_F32,
+                                           L.ptr(m), len(x)))
+
+    # ---- stages ------------------------------------------------------------------------
+    def deposit(self):
+        self._ck(self.lib.pm_deposit(self.ctx))
+
+    def solve_potential(self):
+        self._ck(self.lib.pm_potential(self.ctx))
+
+    def gradient(self):
+        self._ck(self.lib.pm_gradient(self.ctx))
+
+    def compute_forces(self):
+        self._ck(self.lib.pm_forces(self.ctx))
+
+    def gather_kick_drift(self, dt):
+        self._ck(self.lib.pm_gather_kick_drift(self.ctx, float(dt)))
+
+    def step(self, dt, n=1):
+        self._ck(self.lib.pm_step(self.ctx, float(dt), int(n)))
+
+    def synchronize(self):
+        self._ck(self.lib.pm_synchronize(self.ctx))
+
+    def set_flags(self, timing=False, fused_gradient=False):
+        flags = (L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
+        self._ck(self.lib.pm_set_flags(self.ctx, flags))
+
+    # ---- state -------------------------------------------------------------------------
+    def _particles(self, want_pos, want_vel):
+        n = self.n
+        pd, vd = L._int(), L._int()
+        self._ck(self.lib.pm_get_particles(self.ctx, None, pd, None, vd))
+        x = np.empty((n, 3), np.float64 if pd.value == L.PM_F64 else np.float32) if want_pos else None
+        v = np.empty((n, 3), np.float64 if vd.value == L.PM_F64 else np.float32) if want_vel else None
+        self._ck(self.lib.pm_get_particles(self.ctx, L.ptr(x), pd, L.ptr(v), vd))
+        return x, v
+
+    def positions(self):
+        return self._particles(True, False)[0]
+
+    def velocities(self):
+        return self._particles(False, True)[1]
+
+    def forces(self):
+        f = np.empty((self.n, 3), np.float32)
+        self._ck(self.lib.pm_get_forces(self.ctx, L.ptr(f)))
+        return f
+
+    def mesh(self, which):
+        out = np.empty((self.grid_size,) * 3, np.float32)
+        self._ck(self.lib.pm_get_mesh(self.ctx, which, L.ptr(out)))
+        return out
+
+    def set_mesh(self, which, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.shape != (self.grid_size,) * 3:
+            raise ValueError(f"mesh must have shape {(self.grid_size,) * 3}, got {a.shape}")
+        self._ck(self.lib.pm_set_mesh(self.ctx, which, L.ptr(a)))
+
+    def density(self):
+        return self.mesh(L.MESH_DENSITY)
+
+    def potential(self):
+        return self.mesh(L.MESH_POTENTIAL)
+
+    def potential_gradient(self):
+        return tuple(self.mesh(w) for w in (L.MESH_GX, L.MESH_GY, L.MESH_GZ))
+
+    def cell_keys(self):
+        """(keys, perm): cell key of the r-th particle in cell order and its original index."""
+        n = self.n
+        keys, perm = np.empty(n, np.int64), np.empty(n, np.int64)
+        self._ck(self.lib.pm_get_cell_keys(self.ctx, L.ptr(keys), L.ptr(perm)))
+        return keys, perm
+
+    def stage_times(self):
+        """{stage: (milliseconds, calls)} since the last call (needs timing=True)."""
+        ms = np.zeros(len(L.STAGES), np.float32)
+        calls = np.zeros(len(L.STAGES), np.int32)
+        self._ck(self.lib.pm_stage_times(self.ctx, L.ptr(ms), L.ptr(calls)))
+        return {s: (float(ms[i]), int(calls[i])) for i, s in enumerate(L.STAGES)}

@@ -1,0 +1,247 @@
+"""GPU parity: libpm.so (through its C ABI) against the oracle and the golden vectors.
+
+Tolerances (float32 state):
+  * cell keys and cell order: bit-exact;
+  * np.gradient stencil on an identical potential: bit-exact;
+  * CIC gather on an identical gradient: bit-exact (at most 2 ulp is the stated bar);
+  * density: |gpu - ref| <= 2e-5*|ref| + 1e-6*max|ref|, and the GPU's error against a float64
+    deposit must not exceed the reference's own (the reference rounds to float32 at every add,
+    the GPU sums in float64 and rounds once);
+  * potential on an identical density: 1e-5 * max|phi| (pocketfft C2C vs rocFFT R2C/C2R);
+  * positions / velocities after K steps: 1e-5*L and 1e-5*max|v|.
+"""
+import numpy as np
+import pytest
+
+from oracle import pm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pm():
+    import pm as _pm
+    _pm.load()
+    return _pm
+
+
+def ulp_diff(a, b):
+    """Distance in float32 ulps (same-sign finite values)."""
+    ia = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def assert_density(d_gpu, d_ref, d64):
+    tol = 2e-5 * np.abs(d_ref) + 1e-6 * np.abs(d_ref).max()
+    assert np.all(np.abs(d_gpu.astype(np.float64) - d_ref) <= tol)
+    err_gpu = np.abs(d_gpu - d64).max()
+    err_ref = np.abs(d_ref - d64).max()
+    assert err_gpu <= err_ref + np.finfo(np.float32).eps * np.abs(d64).max()
+
+
+@pytest.mark.parametrize("tag", ["64", "32"])
+def test_edge_cases(pm, golden, tag):
+    g = golden("edge_cases_g8.npz")
+    G, L = int(g["G"]), int(g["L"])
+    pos, mass = g["pos" + tag], g["mass" + tag]
+    if tag == "32":
+        assert pos.dtype == np.float32
+    with pm.Simulation(G, L, pos, None, mass) as sim:
+        keys, perm = sim.cell_keys()
+        c = g["cell" + tag].astype(np.int64)
+        ref_keys = (c[:, 0] * G + c[:, 1]) * G + c[:, 2]
+        order = O.sort_order(ref_keys)
+        assert np.array_equal(perm, order) and np.array_equal(keys, ref_keys[order])
+        sim.deposit()
+        assert_density(sim.density(), g["density" + tag], O.CIC_f64(pos, G, L, mass))
+        for w, a in zip((2, 3, 4), (g["gx"], g["gy"], g["gz"])):
+            sim.set_mesh(w, a)
+        sim.compute_forces()
+        assert np.array_equal(sim.forces(), g["forces" + tag])
+
+
+def test_wrap_returns_box_size_like_numpy(pm, golden):
+    g = golden("edge_cases_g8.npz")
+    L = int(g["L"])
+    x = g["wrap_in"].astype(np.float32)
+    n = len(x) - len(x) % 3
+    x3 = x[:n].reshape(-1, 3).copy()
+    with pm.Simulation(8, L, x3, np.zeros_like(x3), None) as sim:
+        for w in (2, 3, 4):
+            sim.set_mesh(w, np.zeros((8, 8, 8), np.float32))
+        sim.gather_kick_drift(0.005)
+        assert np.array_equal(sim.positions().ravel(), g["wrap_out"][:n])
+
+
+@pytest.mark.parametrize("name", ["uniform_n10000_g32.npz", "c1mini_g50.npz"])
+def test_step0_stages(pm, golden, name):
+    from pm import functions as F
+    g = golden(name)
+    G, L = int(g["G"]), int(g["L"])
+    pos, mass = g["pos0"], g["mass"]
+    with pm.Simulation(G, L, pos, g["vel0"], mass) as sim:
+        keys, perm = sim.cell_keys()
+        ref_keys = O.cell_keys(pos, G, L)
+        order = O.sort_order(ref_keys)
+        assert np.array_equal(perm, order) and np.array_equal(keys, ref_keys[order])
+        sim.deposit()
+        assert_density(sim.density(), g["s0_density"], O.CIC_f64(pos, G, L, mass))
+    # each stage on the reference's own input, through the reference-named functions
+    assert_density(F.CIC(pos, G, L, mass), g["s0_density"], O.CIC_f64(pos, G, L, mass))
+    pot = F.compute_potential(g["s0_density"], G)
+    assert pot.dtype == np.float32
+    assert np.abs(pot - g["s0_potential"]).max() <= 1e-5 * np.abs(g["s0_potential"]).max()
+    gx, gy, gz = F.gradient(g["s0_potential"])
+    assert np.array_equal(gx, g["s0_gx"]) and np.array_equal(gy, g["s0_gy"]) and np.array_equal(gz, g["s0_gz"])
+    f = F.force_CIC((g["s0_gx"], g["s0_gy"], g["s0_gz"]), pos, G, L)
+    assert f.dtype == np.float32 and f.shape == (len(pos), 3)
+    assert ulp_diff(f, g["s0_forces"]).max() <= 2
+    assert np.array_equal(f, g["s0_forces"])
+    x1, v1 = F.kick_drift((g["s0_gx"], g["s0_gy"], g["s0_gz"]), pos, g["vel0"], G, L, float(g["dt"]))
+    assert x1.dtype == np.float32 and v1.dtype == g["vel0"].dtype
+    assert np.array_equal(x1, g["x1"]) and np.array_equal(v1, g["v1"])
+    F.release()
+
+
+@pytest.mark.parametrize("name", ["uniform_n10000_g32.npz", "c1mini_g50.npz"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_k_steps(pm, golden, name, fused):
+    g = golden(name)
+    G, L, dt, K = int(g["G"]), int(g["L"]), float(g["dt"]), int(g["K"])
+    with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"], fused_gradient=fused) as sim:
+        for step in range(1, K + 1):
+            sim.step(dt)
+            if f"x{step}" in g:
+                x, v = sim.positions(), sim.velocities()
+                assert x.dtype == np.float32 and v.dtype == g["vel0"].dtype
+                dx = np.abs(x.astype(np.float64) - g[f"x{step}"])
+                dx = np.minimum(dx, L - dx)                      # periodic distance
+                assert dx.max() <= 1e-5 * L, (step, dx.max())
+                vmax = np.abs(g[f"v{step}"]).max()
+                assert np.abs(v - g[f"v{step}"]).max() <= 1e-5 * vmax, (step, np.abs(v - g[f"v{step}"]).max(), vmax)
+
+
+def test_fused_gradient_is_bit_identical(pm, golden):
+    g = golden("uniform_n10000_g32.npz")
+    G, L, dt = int(g["G"]), int(g["L"]), float(g["dt"])
+    out = []
+    for fused in (False, True):
+        with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"], fused_gradient=fused) as sim:
+            sim.step(dt, 5)
+            out.append((sim.positions(), sim.velocities()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_cell_order_over_steps(pm, golden):
+    """Cell order = stable sort by key of the storage order, which is the previous cell order."""
+    g = golden("uniform_n10000_g32.npz")
+    G, L, dt = int(g["G"]), int(g["L"]), float(g["dt"])
+    with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"]) as sim:
+        storage = np.arange(len(g["pos0"]))             # original index of each storage slot
+        for step in range(4):
+            x = sim.positions()                         # original order
+            keys, perm = sim.cell_keys()
+            k_storage = O.cell_keys(x, G, L)[storage]
+            order = O.sort_order(k_storage)
+            storage = storage[order]
+            assert np.array_equal(perm, storage), step
+            assert np.array_equal(keys, k_storage[order]), step
+            sim.step(dt)
+
+
+def test_results_do_not_depend_on_input_order(pm, golden):
+    """Density is summed in cell order, forces are per particle: a shuffled input gives the same
+    trajectories up to the float64 summation order inside a cell."""
+    g = golden("uniform_n10000_g32.npz")
+    G, L, dt = int(g["G"]), int(g["L"]), float(g["dt"])
+    rng = np.random.default_rng(3)
+    p = rng.permutation(len(g["pos0"]))
+    with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"]) as a, \
+            pm.Simulation(G, L, g["pos0"][p], g["vel0"][p], g["mass"][p]) as b:
+        a.step(dt, 3)
+        b.step(dt, 3)
+        assert np.abs(a.positions()[p] - b.positions()).max() <= 1e-6 * L
+
+
+def _uniform(n, L, seed=0):
+    rng = np.random.default_rng(seed)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    vel = rng.normal(0, 10, (n, 3)).astype(np.float32)
+    return pos, vel, np.ones(n, np.float32)
+
+
+def test_full_size_properties(pm):
+    """N = 1M on 128^3 (the correctness configuration): size-independent properties."""
+    n, G, L, dt = 1_000_000, 128, 10000, 0.005
+    pos, vel, mass = _uniform(n, L)
+    with pm.Simulation(G, L, pos, vel, mass) as sim:
+        keys, perm = sim.cell_keys()
+        assert np.all(np.diff(keys) >= 0) and np.array_equal(np.sort(perm), np.arange(n))
+        ref_keys = O.cell_keys(pos, G, L)
+        assert np.array_equal(keys, ref_keys[perm])
+        same = np.diff(keys) == 0
+        assert np.all(np.diff(perm)[same] > 0)                  # ties keep the original order
+        sim.deposit()
+        d = sim.density()
+        assert abs(d.astype(np.float64).sum() - n) <= 1e-6 * n  # sum(density) == sum(mass), no /cell volume
+        assert_density(d, O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
+        # gather of a constant gradient returns the constant (the eight weights sum to 1)
+        for w, c in zip((2, 3, 4), (1.5, -2.0, 0.25)):
+            sim.set_mesh(w, np.full((G, G, G), c, np.float32))
+        sim.compute_forces()
+        f = sim.forces()
+        assert np.abs(f - np.array([1.5, -2.0, 0.25], np.float32)).max() <= 1e-6
+        # one full step against the oracle
+        sim.set_particles(pos, vel, mass)
+        sim.step(dt)
+        xo, vo = O.pm_step(pos, vel, mass, G, L, dt)
+        dx = np.abs(sim.positions().astype(np.float64) - xo)
+        assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+        assert np.abs(sim.velocities() - vo).max() <= 1e-5 * np.abs(vo).max()
+
+
+def test_single_fourier_mode(pm):
+    """A single density mode delta gives delta / k^2 with k in cycles per sample (functions.py:75-85)."""
+    from pm import functions as F
+    G = 64
+    i = np.arange(G)
+    for ax, m in ((0, 3), (1, 5), (2, 1)):
+        shape = [1, 1, 1]
+        shape[ax] = G
+        dens = np.broadcast_to(np.cos(2 * np.pi * m * i / G).reshape(shape), (G, G, G)).astype(np.float32)
+        pot = F.compute_potential(dens, G)
+        want = dens / np.float32((m / G) ** 2)
+        assert np.abs(pot - want).max() <= 2e-5 * np.abs(want).max()
+    F.release()
+
+
+def test_clustered_hot_cell(pm):
+    """Half of the particles in one cell: the wave-cooperative run path of the deposit."""
+    n, G, L = 200_000, 100, 10000
+    rng = np.random.default_rng(5)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    pos[: n // 2] = (5000 + rng.random((n // 2, 3)) * 90).astype(np.float32)
+    mass = (rng.random(n) + 0.5).astype(np.float32)
+    with pm.Simulation(G, L, pos, None, mass) as sim:
+        sim.deposit()
+        assert_density(sim.density(), O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
+
+
+def test_errors(pm):
+    lib = pm.load()
+    assert not lib.pm_create(1, 1.0, 10, 0, 0)
+    assert b"grid_size" in lib.pm_last_error(None)
+    assert not lib.pm_create(8, -1.0, 10, 0, 0)
+    with pm.Simulation(8, 100.0, capacity=4) as sim:
+        with pytest.raises(pm.PMError):
+            sim.deposit()                                   # no particles yet
+        with pytest.raises(pm.PMError):
+            sim.set_particles(np.zeros((5, 3), np.float32)) # beyond capacity
+        sim.set_particles(np.zeros((0, 3), np.float32))     # empty set is fine
+        sim.deposit()
+        assert not sim.density().any()
+        with pytest.raises(pm.PMError):
+            sim.forces()                                    # pm_forces not called

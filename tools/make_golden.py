@@ -127,7 +127,7 @@ def make_uniform():
     rng = np.random.default_rng(0)
     pos = (rng.random((N, 3)) * L).astype(np.float32)
     vel = rng.normal(0.0, 3.0e4, (N, 3)).astype(np.float32)
-    mass = (rng.random(N) + 0.5).astype(np.float32) * np.float32(3.0e5)
+    mass = (rng.random(N) + 0.5).astype(np.float32) * np.float32(3.0e4)
     d = dict(pos0=pos, vel0=vel, mass=mass, G=G, L=L, dt=dt, K=K)
     d.update(run_steps(pos, vel, mass, G, L, dt, K, snaps=(1, 5, 10, 20), full_at=(0, 19)))
     # secondary variants on the same inputs: NGP deposit / force (functions.py:11-16, 92-97)
