@@ -95,7 +95,7 @@ int ensure_binned(pm_ctx *c)
     HIP_TRY(c, pm_launch_cell_keys(c));
     HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
     HIP_TRY(c, pm_launch_reorder(c));
-    HIP_TRY(c, pm_launch_cell_start(c));
+    HIP_TRY(c, pm_launch_row_start(c));
     c->binned = true;
     return PM_OK;
 }
@@ -125,7 +125,7 @@ void pm_destroy(pm_ctx *c)
         hipFree(c->m[u]); hipFree(c->id[u]);
     }
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
-    hipFree(c->cell_start); hipFree(c->gap_list); hipFree(c->gap_count);
+    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->heavy_count); hipFree(c->cell_list); hipFree(c->skip); hipFree(c->pre);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage);
@@ -153,10 +153,12 @@ static int create_impl(pm_ctx *c)
     TRY(dalloc(c, &c->src, cap));
     c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
-    TRY(dalloc(c, &c->cell_start, M + 1));
-    c->gap_cap = (uint32_t)(M / 65536 + 2);
-    TRY(dalloc(c, &c->gap_list, 3 * (size_t)c->gap_cap));
-    TRY(dalloc(c, &c->gap_count, 1));
+    TRY(dalloc(c, &c->row_start, (size_t)G * G + 1));
+    TRY(dalloc(c, &c->heavy_rows, (size_t)G * G));
+    TRY(dalloc(c, &c->heavy_count, 2));
+    TRY(dalloc(c, &c->cell_list, 3 * (cap / 32 + 2)));
+    TRY(dalloc(c, &c->skip, cap));
+    TRY(dalloc(c, &c->pre, 8 * cap));
     TRY(dalloc(c, &c->density, M));
     TRY(dalloc(c, &c->potential, M));
     for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
@@ -187,7 +189,7 @@ pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device
 {
     if (grid_size < 2 || grid_size > 1625) { fail(nullptr, PM_EINVAL, "grid_size must be in [2, 1625] (cell keys are 32-bit)"); return nullptr; }
     if (!(box_size > 0.0) || !std::isfinite(box_size)) { fail(nullptr, PM_EINVAL, "box_size must be positive and finite"); return nullptr; }
-    if (n_capacity < 0 || n_capacity >= ((int64_t)1 << 32) - 1) { fail(nullptr, PM_EINVAL, "n_capacity must be in [0, 2^32-2]"); return nullptr; }
+    if (n_capacity < 0 || n_capacity >= ((int64_t)1 << 31)) { fail(nullptr, PM_EINVAL, "n_capacity must be in [0, 2^31-1]"); return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
         fail(nullptr, PM_EHIP, "no such HIP device: " + std::to_string(device) + " of " + std::to_string(ndev));

@@ -41,17 +41,19 @@ struct pm_ctx {
     bool pos_f64 = false;       // live positions are in xd[]
     bool pos_in_f64 = false;    // dtype given to pm_set_particles
     bool vel_f64 = false;
-    bool binned = false;        // live set is in cell order and cell_start matches it
+    bool binned = false;        // live set is in cell order and row_start matches it
     bool have_forces = false;
 
     // binning scratch
     uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    uint32_t *cell_start = nullptr;     // M + 1 entries
-    uint32_t *gap_list = nullptr;       // big-gap records (lo, hi, value)
-    uint32_t *gap_count = nullptr;
-    uint32_t gap_cap = 0;
+    uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
+    uint32_t *heavy_rows = nullptr;     // density rows fed by more particles than one wave should walk
+    uint32_t *heavy_count = nullptr;    // [0] heavy rows listed, [1] heavy-cell pieces listed
+    uint32_t *cell_list = nullptr;      // (first, one-past-last, piece) of every piece of a heavy cell's run
+    uint32_t *skip = nullptr;           // per particle: 0, or one past its heavy cell's run (+ head bit)
+    double *pre = nullptr;              // [8][cap]: corner sums of the pieces, at first particle + piece
 
     // meshes
     float *density = nullptr, *potential = nullptr, *grad[3] = {};
@@ -79,7 +81,7 @@ hipError_t pm_launch_cell_keys(pm_ctx *c);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);
 size_t pm_sort_tmp_bytes(int64_t cap);
 hipError_t pm_launch_reorder(pm_ctx *c);
-hipError_t pm_launch_cell_start(pm_ctx *c);
+hipError_t pm_launch_row_start(pm_ctx *c);
 hipError_t pm_launch_deposit(pm_ctx *c);
 hipError_t pm_launch_green(pm_ctx *c);
 hipError_t pm_launch_gradient(pm_ctx *c);

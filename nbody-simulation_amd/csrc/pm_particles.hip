@@ -152,118 +152,291 @@ __global__ void k_reorder(reorder_args a)
     a.id_out[r] = a.id_in[s];
 }
 
-// cell_start[c] = number of particles whose key is < c, for c in [0, M]: thread r
-// (0..n) owns the cells in (key[r-1], key[r]].  Short runs of empty cells are
-// written by the owning lane, medium ones by its wave, long ones go to a list
-// that k_fill_gaps spreads over the whole grid.
-constexpr uint32_t GAP_LANE = 64, GAP_WAVE = 65536;
+// row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
+// [0, G*G]: thread r (0..n) owns the rows in (row(key[r-1]), row(key[r])].  Short runs of empty
+// rows are written by the owning lane, longer ones by its wave.
+//
+// The same pass finds the "heavy" cells (more than HEAVY_CELL particles): the thread of a
+// cell's first particle checks key[r + HEAVY_CELL], finds the end of the cell's run by a
+// galloping search, and lists the run in pieces of HEAVY_PIECE particles for k_heavy_cells.
+// It also clears skip[] (k_heavy_cells then marks the particles of heavy cells in it).
+constexpr uint32_t HEAVY_CELL = 64, HEAVY_PIECE = 2048;
+constexpr uint32_t SKIP_HEAD = 0x80000000u;
 
-__global__ void k_cell_start(const uint32_t *__restrict__ key, int64_t n, int64_t M, uint32_t *__restrict__ cs,
-                             uint32_t *__restrict__ gap_list, uint32_t *__restrict__ gap_count, uint32_t gap_cap)
+__global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs,
+                            uint32_t *__restrict__ skip, uint32_t *__restrict__ cell_list, uint32_t *__restrict__ cell_count)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    int64_t lo = 0, hi = 0;
+    uint32_t lo = 0, hi = 0;
     if (r <= n) {
-        lo = (r == 0) ? 0 : (int64_t)key[r - 1] + 1;
-        hi = (r == n) ? M + 1 : (int64_t)key[r] + 1;
-    }
-    int64_t len = hi - lo;
-    if (len > 0 && len <= GAP_LANE)
-        for (int64_t c = lo; c < hi; ++c) cs[c] = (uint32_t)r;
-    if (len > GAP_WAVE) {
-        uint32_t e = atomicAdd(gap_count, 1u);
-        if (e < gap_cap) {      // cannot overflow: at most M / GAP_WAVE + 1 such gaps exist
-            gap_list[3 * e] = (uint32_t)lo; gap_list[3 * e + 1] = (uint32_t)(hi - 1); gap_list[3 * e + 2] = (uint32_t)r;
+        uint32_t kprev = (r == 0) ? 0u : key[r - 1];
+        uint32_t kcur = (r == n) ? 0u : key[r];
+        lo = (r == 0) ? 0u : kprev / G + 1u;
+        hi = (r == n) ? R + 1u : kcur / G + 1u;
+        if (r < n) {
+            skip[r] = 0u;
+            bool head = (r == 0) || kprev != kcur;
+            if (head && r + HEAVY_CELL < n && key[r + HEAVY_CELL] == kcur) {
+                // first index past the run: gallop, then bisect; inside = last index known to hold kcur
+                int64_t inside = r + HEAVY_CELL, step = HEAVY_CELL, outside = n;
+                while (inside + step < n) {
+                    if (key[inside + step] == kcur) { inside += step; step <<= 1; }
+                    else { outside = inside + step; break; }
+                }
+                while (outside - inside > 1) {
+                    int64_t mid = (inside + outside) >> 1;
+                    if (key[mid] == kcur) inside = mid; else outside = mid;
+                }
+                uint32_t len = (uint32_t)(outside - r);
+                uint32_t pieces = (len + HEAVY_PIECE - 1) / HEAVY_PIECE;
+                uint32_t e = atomicAdd(cell_count, pieces);           // at most n / HEAVY_CELL entries in all
+                for (uint32_t p = 0; p < pieces; ++p) {
+                    cell_list[3 * (e + p)] = (uint32_t)r; cell_list[3 * (e + p) + 1] = (uint32_t)outside; cell_list[3 * (e + p) + 2] = p;
+                }
+            }
         }
     }
-    unsigned long long mid = __ballot(len > GAP_LANE && len <= GAP_WAVE);
-    while (mid) {
-        int l = __ffsll((long long)mid) - 1;
-        mid &= mid - 1;
-        int64_t a = __shfl(lo, l), b = __shfl(hi, l);
-        uint32_t v = (uint32_t)__shfl(r, l);
-        for (int64_t c = a + lane_id(); c < b; c += 64) cs[c] = v;
-    }
-}
-
-__global__ void k_fill_gaps(const uint32_t *__restrict__ gap_list, const uint32_t *__restrict__ gap_count,
-                            uint32_t gap_cap, uint32_t *__restrict__ cs)
-{
-    uint32_t cnt = *gap_count;
-    if (cnt > gap_cap) cnt = gap_cap;
-    int64_t stride = (int64_t)gridDim.x * BLOCK;
-    int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    for (uint32_t e = 0; e < cnt; ++e) {
-        int64_t lo = gap_list[3 * e], hi = (int64_t)gap_list[3 * e + 1] + 1;
-        uint32_t v = gap_list[3 * e + 2];
-        for (int64_t c = lo + t; c < hi; c += stride) cs[c] = v;
+    uint32_t len = hi - lo;
+    if (len > 0 && len <= 32u)
+        for (uint32_t c = lo; c < hi; ++c) rs[c] = (uint32_t)r;
+    unsigned long long big = __ballot(len > 32u);
+    while (big) {
+        int l = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        uint32_t a = __shfl(lo, l), b = __shfl(hi, l), v = (uint32_t)__shfl(r, l);
+        for (uint32_t c = a + lane_id(); c < b; c += 64) rs[c] = v;
     }
 }
 
 // ---- CIC deposit ---------------------------------------------------------------------------
 //
-// One thread per mesh cell.  Cell (i,j,k) receives mass from the particles of
-// the eight cells (i-di, j-dj, k-dk), di,dj,dk in {0,1}, each through the
-// corner (di,dj,dk) of its own cloud (functions.py:56-68).  With the particles
-// in cell order those are eight contiguous runs, found through cell_start.  The
-// sum is taken in float64 in a fixed order (corner order of functions.py:61-68,
-// particles in cell order inside a corner) and rounded to float32 once, so the
-// result is deterministic and no atomics are used.  A run longer than RUN_LANE
-// is summed by the whole wave (stride-64 partial sums, then a fixed butterfly).
-constexpr uint32_t RUN_LANE = 32;
+// One wave per mesh row (i,j,:) of the density.  The row receives mass from the particles of
+// the four mesh rows (i-di, j-dj), di,dj in {0,1}, through the corners (di,dj,0) into cell k and
+// (di,dj,1) into cell k+1 of their clouds (functions.py:56-68).  With the particles in cell
+// order each of those rows is one contiguous run of the particle arrays, found through
+// row_start.  The wave walks the four runs, 64 particles at a time, and adds the float64 corner
+// masses into a float64 copy of the row held in LDS; the row is rounded to float32 once, when
+// it is written out.  No global atomics, no mesh-sized index: the only mesh traffic is the one
+// coalesced write of the density.
+//
+// All adds to a row come from one wave, in program order, so the sum has one fixed order.
+// Two things keep dense clumps from serialising the walk:
+//  * heavy cells (more than HEAVY_CELL particles) are summed once, for all eight corners, by
+//    k_heavy_cells (one wave per piece of the cell's run, fixed butterfly); the walk then takes
+//    the cell's sums from pre[] at the cell's first particle and jumps over the rest;
+//  * rows still fed by more than HEAVY_ROW particles are left to k_deposit_heavy, where the
+//    waves of a block each walk a contiguous slice of the runs into their own LDS row and the
+//    slices are added in wave order.
+constexpr uint32_t HEAVY_ROW = 2048;
 
+// The eight corner masses of particle r: mass * wx * wy * wz, left to right (functions.py:61-68),
+// indexed q = di + 2*dj + 4*dk.
 template <typename TP>
-__device__ __forceinline__ double corner_mass(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
-                                              const float *__restrict__ m, uint32_t r, int di, int dj, int dk,
-                                              const pm_geom &g)
+__device__ __forceinline__ void corner_masses(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
+                                              const float *__restrict__ m, uint32_t r, const pm_geom &g, double w[8])
 {
     cell_t c = locate((double)x[r], (double)y[r], (double)z[r], g);
-    double wx = di ? c.dx : 1.0 - c.dx;
-    double wy = dj ? c.dy : 1.0 - c.dy;
-    double wz = dk ? c.dz : 1.0 - c.dz;
-    return (double)m[r] * wx * wy * wz;      // mass * wx * wy * wz, left to right (functions.py:61)
+    double mm = (double)m[r];
+    double mx[2] = {mm * (1.0 - c.dx), mm * c.dx};
+    double wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = mx[q & 1] * wy[(q >> 1) & 1] * wz[q >> 2];
+}
+
+// One wave per listed piece of a heavy cell's run: the eight corner sums of the piece go to
+// pre[q*cap + first particle of the cell + piece number]; skip[] gets, for every particle of the
+// piece, the index one past the cell's run (the cell's first particle also gets SKIP_HEAD).
+template <typename TP>
+__global__ void __launch_bounds__(BLOCK)
+k_heavy_cells(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z, const float *__restrict__ m,
+              const uint32_t *__restrict__ cell_list, const uint32_t *__restrict__ cell_count,
+              double *__restrict__ pre, uint32_t *__restrict__ skip, int64_t cap, pm_geom g)
+{
+    const uint32_t cnt = *cell_count;
+    const uint32_t waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t e = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); e < cnt; e += waves) {
+        const uint32_t beg = cell_list[3 * e], end = cell_list[3 * e + 1], piece = cell_list[3 * e + 2];
+        const uint32_t pb = beg + piece * HEAVY_PIECE;
+        const uint32_t pe = (end - pb > HEAVY_PIECE) ? pb + HEAVY_PIECE : end;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t r = pb + lane_id(); r < pe; r += 64) {
+            double w[8];
+            corner_masses(x, y, z, m, r, g, w);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += w[q];
+            skip[r] = (r == beg) ? (end | SKIP_HEAD) : end;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off);
+        }
+        if (lane_id() < 8) {
+            double v = acc[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v = (lane_id() == q) ? acc[q] : v;
+            pre[(int64_t)lane_id() * cap + beg + piece] = v;
+        }
+    }
+}
+
+// Mass of particle r entering cells k (lo) and k+1 (hi) of the row displaced by (di,dj):
+// mass * wx * wy * wz, left to right (functions.py:61-68).
+template <typename TP>
+__device__ __forceinline__ void row_masses(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
+                                           const float *__restrict__ m, uint32_t r, int di, int dj, const pm_geom &g,
+                                           int &k, double &lo, double &hi)
+{
+    cell_t c = locate((double)x[r], (double)y[r], (double)z[r], g);
+    double w = (double)m[r] * (di ? c.dx : 1.0 - c.dx) * (dj ? c.dy : 1.0 - c.dy);
+    k = c.k;
+    lo = w * (1.0 - c.dz);
+    hi = w * c.dz;
+}
+
+__device__ __forceinline__ void lds_add(double *p, double v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One run of a source row into the LDS row `acc`, 64 particles per pass.  The particles are in
+// cell order, so the lanes of a pass hold non-decreasing k and the lanes that share a cell are
+// neighbours.  Where many lanes share cells their masses are first summed by a segmented scan
+// over the wave (fixed tree order) and only the last lane of every cell adds to LDS; otherwise
+// every lane adds its own.  Particles of a heavy cell are represented by the cell's first
+// particle alone, which adds the sums k_heavy_cells left in pre[]; when a pass ends inside a
+// heavy cell the walk continues after that cell.
+template <typename TP>
+__device__ __forceinline__ void deposit_run(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
+                                            const float *__restrict__ m, const uint32_t *__restrict__ key,
+                                            const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
+                                            uint32_t beg, uint32_t end, int di, int dj, const pm_geom &g, double *acc)
+{
+    const int G = g.G;
+    const int lane = lane_id();
+    const double *pre_lo = pre + (int64_t)(di + 2 * dj) * cap, *pre_hi = pre + (int64_t)(di + 2 * dj + 4) * cap;
+    uint32_t base = beg;
+    while (base < end) {                                        // wave-uniform
+        const uint32_t r = base + lane;
+        const bool live = r < end;
+        const uint32_t sk = live ? skip[r] : 0u;
+        int k = 0x7fffffff - lane;                              // idle lanes: distinct, never equal to a cell
+        double lo = 0.0, hi = 0.0;
+        bool add = false;
+        if (live && sk == 0u) {
+            row_masses(x, y, z, m, r, di, dj, g, k, lo, hi);
+            add = true;
+        } else if (sk & SKIP_HEAD) {
+            const uint32_t cend = sk & ~SKIP_HEAD;
+            k = (int)(key[r] % (uint32_t)G);
+            for (uint32_t p = r; p < r + (cend - r + HEAVY_PIECE - 1) / HEAVY_PIECE; ++p) { lo += pre_lo[p]; hi += pre_hi[p]; }
+            add = true;
+        }
+        int kprev = __shfl_up(k, 1);
+        unsigned long long dup = __ballot(lane > 0 && kprev == k);
+        if (__popcll(dup) > 8) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int ku = __shfl_up(k, d);
+                double lu = __shfl_up(lo, d), hu = __shfl_up(hi, d);
+                if (lane >= d && ku == k) { lo += lu; hi += hu; }
+            }
+            int knext = __shfl_down(k, 1);
+            add = add && (lane == 63 || knext != k);             // last lane of its cell: holds the cell's sum
+        }
+        if (add) {
+            lds_add(&acc[k], lo);
+            lds_add(&acc[(k + 1 == G) ? 0 : k + 1], hi);
+        }
+        const uint32_t sk_last = __shfl(sk, 63) & ~SKIP_HEAD;   // 0 unless the pass ended inside a heavy cell
+        base = (sk_last != 0u) ? sk_last : base + 64;
+    }
+}
+
+struct row_runs { uint32_t beg[4], end[4], total; };
+
+// The four source rows of density row `row`, in the order (di,dj) = (0,0) (1,0) (0,1) (1,1).
+__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uint32_t row, int G)
+{
+    int i = (int)(row / (uint32_t)G), j = (int)(row % (uint32_t)G);
+    int im = (i == 0) ? G - 1 : i - 1, jm = (j == 0) ? G - 1 : j - 1;
+    uint32_t src[4] = {(uint32_t)(i * G + j), (uint32_t)(im * G + j), (uint32_t)(i * G + jm), (uint32_t)(im * G + jm)};
+    row_runs t;
+    t.total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t.beg[q] = rs[src[q]]; t.end[q] = rs[src[q] + 1];
+        t.total += t.end[q] - t.beg[q];
+    }
+    return t;
 }
 
 template <typename TP>
 __global__ void __launch_bounds__(BLOCK)
-k_deposit(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z, const float *__restrict__ m,
-          const uint32_t *__restrict__ cs, float *__restrict__ density, pm_geom g)
+k_deposit_rows(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z, const float *__restrict__ m,
+               const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
+               const uint32_t *__restrict__ rs, float *__restrict__ density, uint32_t *__restrict__ heavy_rows,
+               uint32_t *__restrict__ heavy_count, pm_geom g)
 {
-    int64_t cell = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    bool valid = cell < g.M;
-    int G = g.G;
-    int k = (int)(cell % G), j = (int)((cell / G) % G), i = (int)(cell / ((int64_t)G * G));
-    double acc = 0.0;
-    // corner order of functions.py:61-68: 000 100 010 001 110 101 011 111
-    constexpr int DI[8] = {0, 1, 0, 0, 1, 1, 0, 1}, DJ[8] = {0, 0, 1, 0, 1, 0, 1, 1}, DK[8] = {0, 0, 0, 1, 0, 1, 1, 1};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int di = DI[q], dj = DJ[q], dk = DK[q];
-        uint32_t beg = 0, end = 0;
-        if (valid) {
-            int si = i - di, sj = j - dj, sk = k - dk;
-            if (si < 0) si += G;
-            if (sj < 0) sj += G;
-            if (sk < 0) sk += G;
-            int64_t s = ((int64_t)si * G + sj) * G + sk;
-            beg = cs[s]; end = cs[s + 1];
-        }
-        uint32_t cnt = end - beg;
-        if (cnt <= RUN_LANE)
-            for (uint32_t r = beg; r < end; ++r) acc += corner_mass(x, y, z, m, r, di, dj, dk, g);
-        unsigned long long big = __ballot(cnt > RUN_LANE);
-        while (big) {
-            int l = __ffsll((long long)big) - 1;
-            big &= big - 1;
-            uint32_t b = __shfl(beg, l), e = __shfl(end, l);
-            double part = 0.0;
-            for (uint32_t r = b + lane_id(); r < e; r += 64) part += corner_mass(x, y, z, m, r, di, dj, dk, g);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (lane_id() == l) acc += part;
-        }
+    extern __shared__ double lds_rows[];
+    const int G = g.G;
+    const uint32_t R = (uint32_t)G * (uint32_t)G;
+    const uint32_t row = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (row >= R) return;                              // whole waves leave together; no barrier below
+    double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
+    float *out = density + (size_t)row * G;
+    row_runs t = runs_of(rs, row, G);
+    if (t.total > HEAVY_ROW) {
+        if (lane_id() == 0) heavy_rows[atomicAdd(heavy_count, 1u)] = row;
+        return;
     }
-    if (valid) density[cell] = (float)acc;
+    if (t.total == 0) {
+        for (int c = lane_id(); c < G; c += 64) out[c] = 0.0f;
+        return;
+    }
+    for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[0], t.end[0], 0, 0, g, acc);
+    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[1], t.end[1], 1, 0, g, acc);
+    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[2], t.end[2], 0, 1, g, acc);
+    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[3], t.end[3], 1, 1, g, acc);
+    for (int c = lane_id(); c < G; c += 64) out[c] = (float)acc[c];
+}
+
+template <typename TP>
+__global__ void __launch_bounds__(1024)
+k_deposit_heavy(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z, const float *__restrict__ m,
+                const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
+                const uint32_t *__restrict__ rs, float *__restrict__ density, const uint32_t *__restrict__ heavy_rows,
+                const uint32_t *__restrict__ heavy_count, pm_geom g)
+{
+    extern __shared__ double lds_rows[];
+    const int G = g.G;
+    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6;
+    double *acc = lds_rows + (size_t)w * G;
+    const uint32_t cnt = *heavy_count;
+    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const uint32_t row = heavy_rows[e];
+        row_runs t = runs_of(rs, row, G);
+        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // wave w takes the w-th slice of the run; slices are whole multiples of 64 particles
+            uint32_t len = t.end[q] - t.beg[q];
+            uint32_t sl = ((len + nw - 1) / nw + 63u) & ~63u;
+            uint32_t b = t.beg[q] + (uint32_t)w * sl, e2 = b + sl;
+            if (b > t.end[q]) b = t.end[q];
+            if (e2 > t.end[q]) e2 = t.end[q];
+            deposit_run(x, y, z, m, key, skip, pre, cap, b, e2, q & 1, q >> 1, g, acc);
+        }
+        __syncthreads();
+        float *out = density + (size_t)row * G;
+        for (int c = threadIdx.x; c < G; c += blockDim.x) {
+            double sum = 0.0;
+            for (int v = 0; v < nw; ++v) sum += lds_rows[(size_t)v * G + c];
+            out[c] = (float)sum;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- CIC gather + kick + drift + wrap ------------------------------------------------------
@@ -401,23 +574,51 @@ hipError_t pm_launch_reorder(pm_ctx *c)
     return hipGetLastError();
 }
 
-hipError_t pm_launch_cell_start(pm_ctx *c)
+hipError_t pm_launch_row_start(pm_ctx *c)
 {
-    hipError_t e = hipMemsetAsync(c->gap_count, 0, sizeof(uint32_t), c->stream);
+    const uint32_t G = (uint32_t)c->g.G;
+    hipError_t e = hipMemsetAsync(c->heavy_count, 0, 2 * sizeof(uint32_t), c->stream);     // [0] heavy rows, [1] heavy-cell pieces
     if (e != hipSuccess) return e;
-    k_cell_start<<<grid_for(c->n + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, c->g.M, c->cell_start, c->gap_list, c->gap_count, c->gap_cap);
-    k_fill_gaps<<<2048, BLOCK, 0, c->stream>>>(c->gap_list, c->gap_count, c->gap_cap, c->cell_start);
+    k_row_start<<<grid_for(c->n + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, G, G * G, c->row_start, c->skip, c->cell_list, c->heavy_count + 1);
+    return hipGetLastError();
+}
+
+int pm_heavy_waves(int G)
+{
+    int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double)));
+    return nw > 16 ? 16 : (nw < 1 ? 1 : nw);
+}
+
+template <typename TP>
+static hipError_t deposit_dispatch(pm_ctx *c, const TP *const p[3])
+{
+    const int G = c->g.G;
+    const uint32_t R = (uint32_t)G * (uint32_t)G;
+    const int u = c->cur;
+    hipError_t e = hipMemsetAsync(c->heavy_count, 0, sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) return e;
+    k_heavy_cells<TP><<<1024, BLOCK, 0, c->stream>>>(p[0], p[1], p[2], c->m[u], c->cell_list, c->heavy_count + 1, c->pre, c->skip, c->cap, c->g);
+    const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double);
+    k_deposit_rows<TP><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
+        p[0], p[1], p[2], c->m[u], c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->heavy_rows, c->heavy_count, c->g);
+    const int nw = pm_heavy_waves(G);
+    const size_t lds_heavy = (size_t)nw * G * sizeof(double);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[sizeof(TP) == 8]) {
+        e = hipFuncSetAttribute((const void *)k_deposit_heavy<TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[sizeof(TP) == 8] = true;
+    }
+    k_deposit_heavy<TP><<<512, nw * 64, lds_heavy, c->stream>>>(p[0], p[1], p[2], c->m[u], c->key_out, c->skip, c->pre, c->cap,
+                                                                c->row_start, c->density, c->heavy_rows, c->heavy_count, c->g);
     return hipGetLastError();
 }
 
 hipError_t pm_launch_deposit(pm_ctx *c)
 {
     int u = c->cur;
-    if (c->pos_f64)
-        k_deposit<double><<<grid_for(c->g.M), BLOCK, 0, c->stream>>>(c->xd[u][0], c->xd[u][1], c->xd[u][2], c->m[u], c->cell_start, c->density, c->g);
-    else
-        k_deposit<float><<<grid_for(c->g.M), BLOCK, 0, c->stream>>>(c->x[u][0], c->x[u][1], c->x[u][2], c->m[u], c->cell_start, c->density, c->g);
-    return hipGetLastError();
+    if (c->pos_f64) return deposit_dispatch<double>(c, c->xd[u]);
+    return deposit_dispatch<float>(c, c->x[u]);
 }
 
 template <typename TP, typename TV>

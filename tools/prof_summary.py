@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Print the per-kernel summary of a rocprofv3 --kernel-trace --stats CSV directory."""
+import csv
+import glob
+import sys
+
+d = sys.argv[1]
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+print(f"{'kernel':80s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>9s} {'%':>6s}")
+for r in rows[:top]:
+    print(f"{r['Name'][:80]:80s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.1f} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['Percentage']):6.2f}")
