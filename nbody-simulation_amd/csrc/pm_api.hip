@@ -126,7 +126,7 @@ void pm_destroy(pm_ctx *c)
     }
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
     hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->heavy_count); hipFree(c->cell_list); hipFree(c->skip); hipFree(c->pre);
-    hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum);
+    hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage);
     if (c->info) rocfft_execution_info_destroy(c->info);
@@ -162,16 +162,35 @@ static int create_impl(pm_ctx *c)
     TRY(dalloc(c, &c->density, M));
     TRY(dalloc(c, &c->potential, M));
     for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
-    TRY(dalloc(c, &c->spectrum, (size_t)G * G * c->g.Gh));
+    TRY(dalloc(c, &c->spectrum, (size_t)G * G * c->g.Ghp));
     TRY(dalloc(c, &c->forces, 3 * cap));
     HIP_TRY(c, hipMalloc(&c->stage, cap * 3 * sizeof(double) + 16));
 
     std::call_once(g_fft_once, [] { rocfft_setup(); });
-    const size_t lengths[3] = {(size_t)G, (size_t)G, (size_t)G};
-    FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                  rocfft_precision_single, 3, lengths, 1, nullptr));
-    FFT_TRY(c, rocfft_plan_create(&c->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                  rocfft_precision_single, 3, lengths, 1, nullptr));
+    if (c->fft_custom) {
+        // z axis: batched 1-D real transforms, one per mesh row, into / out of rows of pitch Ghp
+        HIP_TRY(c, pm_fft_upload_twiddles(c));
+        const size_t len1[1] = {(size_t)G}, one[1] = {1};
+        rocfft_plan_description df = nullptr, di = nullptr;
+        FFT_TRY(c, rocfft_plan_description_create(&df));
+        FFT_TRY(c, rocfft_plan_description_set_data_layout(df, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
+                                                           nullptr, nullptr, 1, one, (size_t)G, 1, one, (size_t)c->g.Ghp));
+        FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                      rocfft_precision_single, 1, len1, (size_t)G * G, df));
+        FFT_TRY(c, rocfft_plan_description_create(&di));
+        FFT_TRY(c, rocfft_plan_description_set_data_layout(di, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
+                                                           nullptr, nullptr, 1, one, (size_t)c->g.Ghp, 1, one, (size_t)G));
+        FFT_TRY(c, rocfft_plan_create(&c->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                      rocfft_precision_single, 1, len1, (size_t)G * G, di));
+        rocfft_plan_description_destroy(df);
+        rocfft_plan_description_destroy(di);
+    } else {
+        const size_t lengths[3] = {(size_t)G, (size_t)G, (size_t)G};
+        FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                      rocfft_precision_single, 3, lengths, 1, nullptr));
+        FFT_TRY(c, rocfft_plan_create(&c->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                      rocfft_precision_single, 3, lengths, 1, nullptr));
+    }
     size_t wf = 0, wi = 0;
     FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->fwd, &wf));
     FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->inv, &wi));
@@ -197,6 +216,8 @@ pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device
     }
     pm_ctx *c = new pm_ctx;
     c->g.G = grid_size; c->g.Gh = grid_size / 2 + 1;
+    c->fft_custom = pm_fft_custom_supported(grid_size) && !(flags & PM_FLAG_ROCFFT_ONLY);
+    c->g.Ghp = c->fft_custom ? pm_fft_pitch(grid_size) : c->g.Gh;
     c->g.M = (int64_t)grid_size * grid_size * grid_size;
     c->g.L = box_size; c->g.inv = (double)grid_size / box_size; c->g.Lf = (float)box_size;
     c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
@@ -268,13 +289,16 @@ int pm_potential(pm_ctx *c)
         stage_timer t(c, PM_STAGE_FFT_FWD);
         void *in[1] = {c->density}, *out[1] = {c->spectrum};
         FFT_TRY(c, rocfft_execute(c->fwd, in, out, c->info));
+        if (c->fft_custom) HIP_TRY(c, pm_launch_col_fft(c, -1));
     }
     {
         stage_timer t(c, PM_STAGE_GREEN);
-        HIP_TRY(c, pm_launch_green(c));
+        if (c->fft_custom) HIP_TRY(c, pm_launch_col_fft(c, 0));
+        else HIP_TRY(c, pm_launch_green(c));
     }
     {
         stage_timer t(c, PM_STAGE_FFT_INV);
+        if (c->fft_custom) HIP_TRY(c, pm_launch_col_fft(c, 1));
         void *in[1] = {c->spectrum}, *out[1] = {c->potential};
         FFT_TRY(c, rocfft_execute(c->inv, in, out, c->info));
     }
@@ -419,7 +443,8 @@ int pm_get_cell_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
 int pm_set_flags(pm_ctx *c, unsigned flags)
 {
     if (!c) return PM_EINVAL;
-    if (flags & ~(unsigned)(PM_FLAG_TIMING | PM_FLAG_FUSED_GRADIENT)) return fail(c, PM_EINVAL, "unknown flag bits");
+    if (flags & ~(unsigned)(PM_FLAG_TIMING | PM_FLAG_FUSED_GRADIENT)) return fail(c, PM_EINVAL, "only PM_FLAG_TIMING and PM_FLAG_FUSED_GRADIENT can change");
+    flags |= c->flags & PM_FLAG_ROCFFT_ONLY;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < PM_NSTAGES; ++s) stage_timer::flush(c, s);

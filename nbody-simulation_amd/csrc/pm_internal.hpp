@@ -14,6 +14,7 @@
 struct pm_geom {
     int G;          // cells per side
     int Gh;         // G/2 + 1: length of the half-spectrum's fastest axis
+    int Ghp;        // row pitch of the half spectrum in complex elements (>= Gh)
     int64_t M;      // G^3
     double L;       // box size
     double inv;     // G / L, the float64 quotient of functions.py:23
@@ -57,7 +58,9 @@ struct pm_ctx {
 
     // meshes
     float *density = nullptr, *potential = nullptr, *grad[3] = {};
-    float2 *spectrum = nullptr;
+    float2 *spectrum = nullptr;         // (G, G, Ghp) complex64
+    float2 *twiddle = nullptr;          // exp(-2 pi i q / G), q < G (column FFT kernels)
+    bool fft_custom = false;            // z axis by rocFFT (batched 1-D), y and x axes by the column kernels
     rocfft_plan fwd = nullptr, inv = nullptr;
     rocfft_execution_info info = nullptr;
     void *fft_work = nullptr;
@@ -84,6 +87,10 @@ hipError_t pm_launch_reorder(pm_ctx *c);
 hipError_t pm_launch_row_start(pm_ctx *c);
 hipError_t pm_launch_deposit(pm_ctx *c);
 hipError_t pm_launch_green(pm_ctx *c);
+bool pm_fft_custom_supported(int G);
+int pm_fft_pitch(int G);
+hipError_t pm_fft_upload_twiddles(pm_ctx *c);
+hipError_t pm_launch_col_fft(pm_ctx *c, int dir);
 hipError_t pm_launch_gradient(pm_ctx *c);
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);
 hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, bool pos_f64, void *vel_aos);

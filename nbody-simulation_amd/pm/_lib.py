@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpm.so")
 
 PM_F32, PM_F64 = 0, 1
 MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ = range(5)
-FLAG_TIMING, FLAG_FUSED_GRADIENT = 1, 2
+FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY = 1, 2, 4
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
 
 _c_p = ctypes.c_void_p

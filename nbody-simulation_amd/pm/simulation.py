@@ -10,14 +10,15 @@ class Simulation:
     and masses are the bare arrays of main.py:25-33, in their dtypes (float32 or float64)."""
 
     def __init__(self, grid_size, box_size, positions=None, velocities=None, masses=None,
-                 interpolation="CIC", capacity=None, device=0, timing=False, fused_gradient=False):
+                 interpolation="CIC", capacity=None, device=0, timing=False, fused_gradient=False, rocfft_only=False):
         if interpolation != "CIC":
             raise NotImplementedError("only the CIC branch (main.py:9 default) runs on the GPU path")
         self.lib = L.load()
         self.grid_size, self.box_size = int(grid_size), box_size
         n = 0 if positions is None else len(positions)
         self.capacity = int(capacity if capacity is not None else max(n, 1))
-        flags = (L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
+        flags = ((L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
+                 | (L.FLAG_ROCFFT_ONLY if rocfft_only else 0))
         self.ctx = self.lib.pm_create(self.grid_size, float(box_size), self.capacity, int(device), flags)
         if not self.ctx:
             raise L.PMError("pm_create failed: " + self.lib.pm_last_error(None).decode())
