@@ -77,13 +77,9 @@ int alloc_particles(pm_ctx *c)
 {
     size_t cap = (size_t)c->cap;
     for (int u = 0; u < 2; ++u) {
-        for (int d = 0; d < 3; ++d) {
-            TRY(dalloc(c, &c->x[u][d], cap));
-            if (c->pos_in_f64) TRY(dalloc(c, &c->xd[u][d], cap));
-            if (c->vel_f64) TRY(dalloc(c, &c->vd[u][d], cap)); else TRY(dalloc(c, &c->vf[u][d], cap));
-        }
-        TRY(dalloc(c, &c->m[u], cap));
-        TRY(dalloc(c, &c->id[u], cap));
+        TRY(dalloc(c, &c->pf[u], cap));
+        if (c->pos_in_f64) TRY(dalloc(c, &c->pd[u], cap));
+        if (c->vel_f64) TRY(dalloc(c, &c->vd[u], cap)); else TRY(dalloc(c, &c->vf[u], cap));
     }
     return PM_OK;
 }
@@ -103,7 +99,7 @@ int ensure_binned(pm_ctx *c)
 int need_particles(pm_ctx *c)
 {
     if (!c) return PM_EINVAL;
-    if (!c->m[0]) return fail(c, PM_ESTATE, "no particles: call pm_set_particles first");
+    if (!c->pf[0]) return fail(c, PM_ESTATE, "no particles: call pm_set_particles first");
     return PM_OK;
 }
 
@@ -120,12 +116,9 @@ void pm_destroy(pm_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (int u = 0; u < 2; ++u) {
-        for (int d = 0; d < 3; ++d) { hipFree(c->x[u][d]); hipFree(c->xd[u][d]); hipFree(c->vf[u][d]); hipFree(c->vd[u][d]); }
-        hipFree(c->m[u]); hipFree(c->id[u]);
-    }
+    for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
-    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->heavy_count); hipFree(c->cell_list); hipFree(c->skip); hipFree(c->pre);
+    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->piece_list); hipFree(c->skip); hipFree(c->pre);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage);
@@ -155,8 +148,8 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, (size_t)G * G + 1));
     TRY(dalloc(c, &c->heavy_rows, (size_t)G * G));
-    TRY(dalloc(c, &c->heavy_count, 2));
-    TRY(dalloc(c, &c->cell_list, 3 * (cap / 32 + 2)));
+    TRY(dalloc(c, &c->counters, 2));
+    TRY(dalloc(c, &c->piece_list, cap / 64 + cap / 2048 + 2));
     TRY(dalloc(c, &c->skip, cap));
     TRY(dalloc(c, &c->pre, 8 * cap));
     TRY(dalloc(c, &c->density, M));
@@ -164,7 +157,7 @@ static int create_impl(pm_ctx *c)
     for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
     TRY(dalloc(c, &c->spectrum, (size_t)G * G * c->g.Ghp));
     TRY(dalloc(c, &c->forces, 3 * cap));
-    HIP_TRY(c, hipMalloc(&c->stage, cap * 3 * sizeof(double) + 16));
+    HIP_TRY(c, hipMalloc(&c->stage, cap * 32 + 16));
 
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     if (c->fft_custom) {
@@ -250,22 +243,17 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     c->vel_f64 = (vel_dtype == PM_F64);
     TRY(alloc_particles(c));
     c->n = n; c->cur = 0; c->binned = false; c->have_forces = false;
-    const int u = 0;
     size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
     if (n > 0) {
-        HIP_TRY(c, hipMemcpyAsync(c->stage, pos, (size_t)n * 3 * ps, hipMemcpyHostToDevice, c->stream));
-        void *dst[3];
-        for (int d = 0; d < 3; ++d) dst[d] = c->pos_f64 ? (void *)c->xd[u][d] : (void *)c->x[u][d];
-        HIP_TRY(c, pm_launch_aos_to_soa(c, c->stage, c->pos_f64, dst, n));
+        // staging: positions (n,3), then the masses behind them
+        char *st = (char *)c->stage;
+        float *dmass = (float *)(st + (size_t)n * 24);
+        HIP_TRY(c, hipMemcpyAsync(st, pos, (size_t)n * 3 * ps, hipMemcpyHostToDevice, c->stream));
+        if (mass) HIP_TRY(c, hipMemcpyAsync(dmass, mass, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, pm_launch_pack(c, st, mass ? dmass : nullptr, nullptr));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (vel) {
-            HIP_TRY(c, hipMemcpyAsync(c->stage, vel, (size_t)n * 3 * vs, hipMemcpyHostToDevice, c->stream));
-            for (int d = 0; d < 3; ++d) dst[d] = c->vel_f64 ? (void *)c->vd[u][d] : (void *)c->vf[u][d];
-            HIP_TRY(c, pm_launch_aos_to_soa(c, c->stage, c->vel_f64, dst, n));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
-        if (mass) HIP_TRY(c, hipMemcpyAsync(c->m[u], mass, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, pm_launch_fill_particles_defaults(c, vel == nullptr, mass == nullptr));
+        if (vel) HIP_TRY(c, hipMemcpyAsync(st, vel, (size_t)n * 3 * vs, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, pm_launch_pack(c, nullptr, nullptr, vel ? st : nullptr));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return PM_OK;
@@ -363,12 +351,12 @@ int pm_get_particles(pm_ctx *c, void *pos, int *pos_dtype, void *vel, int *vel_d
     if (pos_dtype) *pos_dtype = c->pos_f64 ? PM_F64 : PM_F32;
     if (vel_dtype) *vel_dtype = c->vel_f64 ? PM_F64 : PM_F32;
     if (pos && n) {
-        HIP_TRY(c, pm_launch_export_particles(c, c->stage, c->pos_f64, nullptr));
+        HIP_TRY(c, pm_launch_export_particles(c, c->stage, nullptr));
         HIP_TRY(c, hipMemcpyAsync(pos, c->stage, n * 3 * (c->pos_f64 ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     if (vel && n) {
-        HIP_TRY(c, pm_launch_export_particles(c, nullptr, false, c->stage));
+        HIP_TRY(c, pm_launch_export_particles(c, nullptr, c->stage));
         HIP_TRY(c, hipMemcpyAsync(vel, c->stage, n * 3 * (c->vel_f64 ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }

@@ -21,6 +21,17 @@ struct pm_geom {
     float Lf;       // (float)L for the float32 remainder of main.py:60
 };
 
+// Particle records.  A particle is two 16-byte records (32-byte ones while a coordinate is
+// float64): position + mass, and velocity + the particle's index in the caller's order.  Every
+// kernel moves a record with one or two 16-byte accesses, and the reorder into cell order
+// touches two lines per particle instead of eight.
+template <typename T> struct pm_prec;
+template <> struct alignas(16) pm_prec<float> { float x, y, z, m; };
+template <> struct alignas(16) pm_prec<double> { double x, y, z; float m; float pad; };
+template <typename T> struct pm_vrec;
+template <> struct alignas(16) pm_vrec<float> { float x, y, z; uint32_t id; };
+template <> struct alignas(16) pm_vrec<double> { double x, y, z; uint32_t id; uint32_t pad; };
+
 struct pm_ctx {
     pm_geom g{};
     int device = 0;
@@ -29,17 +40,15 @@ struct pm_ctx {
     int64_t n = 0;      // particles held
     hipStream_t stream = nullptr;
 
-    // Particle state, SoA, double-buffered: `cur` is the live set, 1-cur the
-    // target of the next reorder.  Positions are float32 except between
-    // pm_set_particles(PM_F64) and the first drift, when xd[] holds them.
+    // Particle state, double-buffered: `cur` is the live set, 1-cur the target of the next
+    // reorder.  Positions are float32 except between pm_set_particles(PM_F64) and the first
+    // drift, when pd[] holds them.
     int cur = 0;
-    float *x[2][3] = {};
-    double *xd[2][3] = {};
-    float *vf[2][3] = {};
-    double *vd[2][3] = {};
-    float *m[2] = {};
-    uint32_t *id[2] = {};
-    bool pos_f64 = false;       // live positions are in xd[]
+    pm_prec<float> *pf[2] = {};
+    pm_prec<double> *pd[2] = {};
+    pm_vrec<float> *vf[2] = {};
+    pm_vrec<double> *vd[2] = {};
+    bool pos_f64 = false;       // live positions are in pd[]
     bool pos_in_f64 = false;    // dtype given to pm_set_particles
     bool vel_f64 = false;
     bool binned = false;        // live set is in cell order and row_start matches it
@@ -51,10 +60,10 @@ struct pm_ctx {
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
     uint32_t *heavy_rows = nullptr;     // density rows fed by more particles than one wave should walk
-    uint32_t *heavy_count = nullptr;    // [0] heavy rows listed, [1] heavy-cell pieces listed
-    uint32_t *cell_list = nullptr;      // (first, one-past-last, piece) of every piece of a heavy cell's run
-    uint32_t *skip = nullptr;           // per particle: 0, or one past its heavy cell's run (+ head bit)
-    double *pre = nullptr;              // [8][cap]: corner sums of the pieces, at first particle + piece
+    uint32_t *counters = nullptr;       // [0] heavy rows listed, [1] heavy-cell pieces listed
+    uint32_t *piece_list = nullptr;     // first particle of every piece of a heavy cell's run
+    uint32_t *skip = nullptr;           // per particle: 0, or one past its piece of a heavy cell (+ head bit)
+    double *pre = nullptr;              // [8][cap]: corner sums of a piece, at the piece's first particle
 
     // meshes
     float *density = nullptr, *potential = nullptr, *grad[3] = {};
@@ -67,7 +76,7 @@ struct pm_ctx {
     size_t fft_work_bytes = 0;
 
     float *forces = nullptr;            // (n,3) AoS in storage order
-    void *stage = nullptr;              // AoS staging for host copies, cap*3*8 bytes
+    void *stage = nullptr;              // staging for host copies: cap * 32 bytes
 
     hipEvent_t ev[PM_NSTAGES][2] = {};
     bool ev_used[PM_NSTAGES] = {};
@@ -78,8 +87,8 @@ struct pm_ctx {
 };
 
 // ---- launchers (each enqueues on ctx->stream and returns a hipError_t) ----------------------
-hipError_t pm_launch_aos_to_soa(pm_ctx *c, const void *aos, bool f64, void *const dst[3], int64_t n);
-hipError_t pm_launch_fill_particles_defaults(pm_ctx *c, bool zero_vel, bool ones_mass);
+// stage -> records: positions (n,3) of the given dtype + masses (or ones), velocities (or zeros) + iota ids
+hipError_t pm_launch_pack(pm_ctx *c, const void *pos_aos, const float *mass, const void *vel_aos);
 hipError_t pm_launch_cell_keys(pm_ctx *c);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);
 size_t pm_sort_tmp_bytes(int64_t cap);
@@ -93,6 +102,6 @@ hipError_t pm_fft_upload_twiddles(pm_ctx *c);
 hipError_t pm_launch_col_fft(pm_ctx *c, int dir);
 hipError_t pm_launch_gradient(pm_ctx *c);
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);
-hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, bool pos_f64, void *vel_aos);
+hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos);
 hipError_t pm_launch_export_forces(pm_ctx *c, float *aos);
 hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm);

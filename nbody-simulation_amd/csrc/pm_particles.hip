@@ -1,11 +1,10 @@
-// Particle-side kernels of the PM step for gfx950: cell keys, reorder into
-// cell order, cell-start table, CIC deposit (cell-centric, no float atomics),
-// CIC gather fused with kick / drift / wrap, and the host-copy helpers.
+// Particle-side kernels of the PM step for gfx950: cell keys, reorder into cell order, row-start
+// table, CIC deposit (row-centric, LDS accumulation, no global atomics), CIC gather fused with
+// kick / drift / wrap, and the host-copy helpers.
 //
-// Arithmetic follows what numba compiles the reference loops to
-// (functions.py:19-70, 99-180): wrap, scale, fractional parts and weights in
-// float64; this file is built with -ffp-contract=off so no product is fused
-// into an add.
+// Arithmetic follows what numba compiles the reference loops to (functions.py:19-70, 99-180):
+// wrap, scale, fractional parts and weights in float64; this file is built with
+// -ffp-contract=off so no product is fused into an add.
 #include "pm_internal.hpp"
 
 namespace {
@@ -45,8 +44,8 @@ struct cell_t {
     double dx, dy, dz;
 };
 
-// functions.py:27-43.  A scaled coordinate that rounds up to G (the reference
-// would index out of bounds there) is folded back to cell 0 of that axis.
+// functions.py:27-43.  A scaled coordinate that rounds up to G (the reference would index out
+// of bounds there) is folded back to cell 0 of that axis.
 __device__ __forceinline__ cell_t locate(double px, double py, double pz, const pm_geom &g)
 {
     cell_t c;
@@ -61,113 +60,117 @@ __device__ __forceinline__ cell_t locate(double px, double py, double pz, const 
     return c;
 }
 
+template <typename TP>
+__device__ __forceinline__ cell_t locate(const pm_prec<TP> &p, const pm_geom &g)
+{
+    return locate((double)p.x, (double)p.y, (double)p.z, g);
+}
+
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
+
 // ---- host copies ---------------------------------------------------------------------------
 
-template <typename TI, typename TO>
-__global__ void k_aos_to_soa(const TI *__restrict__ aos, TO *__restrict__ a, TO *__restrict__ b, TO *__restrict__ c, int64_t n)
+template <typename TP>
+__global__ void k_pack_pos(const TP *__restrict__ aos, const float *__restrict__ mass, pm_prec<TP> *__restrict__ P, int64_t n)
 {
     int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n) return;
-    a[p] = (TO)aos[3 * p]; b[p] = (TO)aos[3 * p + 1]; c[p] = (TO)aos[3 * p + 2];
+    pm_prec<TP> rec{};
+    rec.x = aos[3 * p]; rec.y = aos[3 * p + 1]; rec.z = aos[3 * p + 2];
+    rec.m = mass ? mass[p] : 1.0f;
+    P[p] = rec;
 }
 
-template <typename T>
-__global__ void k_fill(T *__restrict__ a, T v, int64_t n)
+template <typename TV>
+__global__ void k_pack_vel(const TV *__restrict__ aos, pm_vrec<TV> *__restrict__ V, int64_t n)
 {
     int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (p < n) a[p] = v;
+    if (p >= n) return;
+    pm_vrec<TV> rec{};
+    if (aos) { rec.x = aos[3 * p]; rec.y = aos[3 * p + 1]; rec.z = aos[3 * p + 2]; }
+    rec.id = (uint32_t)p;
+    V[p] = rec;
 }
 
-__global__ void k_iota(uint32_t *__restrict__ a, int64_t n)
-{
-    int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (p < n) a[p] = (uint32_t)p;
-}
-
-template <typename TI, typename TO>
-__global__ void k_soa_to_aos_by_id(const TI *__restrict__ a, const TI *__restrict__ b, const TI *__restrict__ c,
-                                   const uint32_t *__restrict__ id, TO *__restrict__ aos, int64_t n)
+template <typename TP, typename TV>
+__global__ void k_export_pos(const pm_prec<TP> *__restrict__ P, const pm_vrec<TV> *__restrict__ V, TP *__restrict__ aos, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
-    int64_t o = 3 * (int64_t)id[r];
-    aos[o] = (TO)a[r]; aos[o + 1] = (TO)b[r]; aos[o + 2] = (TO)c[r];
+    pm_prec<TP> rec = P[r];
+    int64_t o = 3 * (int64_t)V[r].id;
+    aos[o] = rec.x; aos[o + 1] = rec.y; aos[o + 2] = rec.z;
 }
 
-__global__ void k_aos_by_id(const float *__restrict__ in, const uint32_t *__restrict__ id, float *__restrict__ out, int64_t n)
+template <typename TV>
+__global__ void k_export_vel(const pm_vrec<TV> *__restrict__ V, TV *__restrict__ aos, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
-    int64_t o = 3 * (int64_t)id[r];
+    pm_vrec<TV> rec = V[r];
+    int64_t o = 3 * (int64_t)rec.id;
+    aos[o] = rec.x; aos[o + 1] = rec.y; aos[o + 2] = rec.z;
+}
+
+template <typename TV>
+__global__ void k_export_forces(const float *__restrict__ in, const pm_vrec<TV> *__restrict__ V, float *__restrict__ out, int64_t n)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    int64_t o = 3 * (int64_t)V[r].id;
     out[o] = in[3 * r]; out[o + 1] = in[3 * r + 1]; out[o + 2] = in[3 * r + 2];
 }
 
-__global__ void k_export_keys(const uint32_t *__restrict__ key, const uint32_t *__restrict__ id,
+template <typename TV>
+__global__ void k_export_keys(const uint32_t *__restrict__ key, const pm_vrec<TV> *__restrict__ V,
                               int64_t *__restrict__ keys, int64_t *__restrict__ perm, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
     keys[r] = (int64_t)key[r];
-    perm[r] = (int64_t)id[r];
+    perm[r] = (int64_t)V[r].id;
 }
 
 // ---- binning -------------------------------------------------------------------------------
 
 template <typename TP>
-__global__ void k_cell_keys(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
-                            uint32_t *__restrict__ key, int64_t n, pm_geom g)
+__global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restrict__ key, int64_t n, pm_geom g)
 {
     int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n) return;
-    cell_t c = locate((double)x[p], (double)y[p], (double)z[p], g);
+    cell_t c = locate(P[p], g);
     key[p] = (uint32_t)(((int64_t)c.i * g.G + c.j) * g.G + c.k);
 }
 
-template <typename T>
-__device__ __forceinline__ void move3(T *const dst[3], T *const src[3], int64_t r, int64_t s)
-{
-    dst[0][r] = src[0][s]; dst[1][r] = src[1][s]; dst[2][r] = src[2][s];
-}
-
-struct reorder_args {
-    float *x_in[3], *x_out[3];
-    double *xd_in[3], *xd_out[3];
-    float *vf_in[3], *vf_out[3];
-    double *vd_in[3], *vd_out[3];
-    float *m_in, *m_out;
-    uint32_t *id_in, *id_out;
-    const uint32_t *src;
-    int64_t n;
-    bool pos_f64, vel_f64;
-};
-
-__global__ void k_reorder(reorder_args a)
+template <typename TP, typename TV>
+__global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
+                          const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__restrict__ Vout,
+                          const uint32_t *__restrict__ src, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= a.n) return;
-    int64_t s = a.src[r];
-    if (a.pos_f64) move3(a.xd_out, a.xd_in, r, s); else move3(a.x_out, a.x_in, r, s);
-    if (a.vel_f64) move3(a.vd_out, a.vd_in, r, s); else move3(a.vf_out, a.vf_in, r, s);
-    a.m_out[r] = a.m_in[s];
-    a.id_out[r] = a.id_in[s];
+    if (r >= n) return;
+    int64_t s = src[r];
+    Pout[r] = Pin[s];
+    Vout[r] = Vin[s];
 }
 
 // row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
 // [0, G*G]: thread r (0..n) owns the rows in (row(key[r-1]), row(key[r])].  Short runs of empty
 // rows are written by the owning lane, longer ones by its wave.
 //
-// The same pass finds the "heavy" cells (more than HEAVY_CELL particles): the thread of a
-// cell's first particle checks key[r + HEAVY_CELL], finds the end of the cell's run by a
-// galloping search, and lists the run in pieces of HEAVY_PIECE particles for k_heavy_cells.
-// It also clears skip[] (k_heavy_cells then marks the particles of heavy cells in it).
+// The same pass cuts the runs of "heavy" cells (more than HEAVY_CELL particles) into pieces for
+// k_heavy_pieces: a piece starts at the cell's first particle and at every multiple of
+// HEAVY_PIECE inside the run.  It also clears skip[] (k_heavy_pieces then marks the particles of
+// heavy cells in it).
 constexpr uint32_t HEAVY_CELL = 64, HEAVY_PIECE = 2048;
 constexpr uint32_t SKIP_HEAD = 0x80000000u;
 
 __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs,
-                            uint32_t *__restrict__ skip, uint32_t *__restrict__ cell_list, uint32_t *__restrict__ cell_count)
+                            uint32_t *__restrict__ skip, uint32_t *__restrict__ piece_list, uint32_t *__restrict__ piece_count)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     uint32_t lo = 0, hi = 0;
+    bool piece = false;
     if (r <= n) {
         uint32_t kprev = (r == 0) ? 0u : key[r - 1];
         uint32_t kcur = (r == n) ? 0u : key[r];
@@ -176,25 +179,26 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
         if (r < n) {
             skip[r] = 0u;
             bool head = (r == 0) || kprev != kcur;
-            if (head && r + HEAVY_CELL < n && key[r + HEAVY_CELL] == kcur) {
-                // first index past the run: gallop, then bisect; inside = last index known to hold kcur
-                int64_t inside = r + HEAVY_CELL, step = HEAVY_CELL, outside = n;
-                while (inside + step < n) {
-                    if (key[inside + step] == kcur) { inside += step; step <<= 1; }
-                    else { outside = inside + step; break; }
-                }
-                while (outside - inside > 1) {
-                    int64_t mid = (inside + outside) >> 1;
-                    if (key[mid] == kcur) inside = mid; else outside = mid;
-                }
-                uint32_t len = (uint32_t)(outside - r);
-                uint32_t pieces = (len + HEAVY_PIECE - 1) / HEAVY_PIECE;
-                uint32_t e = atomicAdd(cell_count, pieces);           // at most n / HEAVY_CELL entries in all
-                for (uint32_t p = 0; p < pieces; ++p) {
-                    cell_list[3 * (e + p)] = (uint32_t)r; cell_list[3 * (e + p) + 1] = (uint32_t)outside; cell_list[3 * (e + p) + 2] = p;
-                }
+            if (head) {
+                piece = (r + HEAVY_CELL < n) && key[r + HEAVY_CELL] == kcur;      // run longer than HEAVY_CELL
+            } else if (r % HEAVY_PIECE == 0) {
+                // a cut inside a run: the run is heavy iff it has more than HEAVY_CELL members; count up to
+                // HEAVY_CELL + 1 of them around the cut
+                uint32_t cnt = 0;
+                for (int64_t q = r - 1; q >= 0 && cnt <= HEAVY_CELL && key[q] == kcur; --q) ++cnt;
+                for (int64_t q = r; q < n && cnt <= HEAVY_CELL && key[q] == kcur; ++q) ++cnt;
+                piece = cnt > HEAVY_CELL;
             }
         }
+    }
+    // one atomic per wave: at most n / HEAVY_CELL + n / HEAVY_PIECE pieces in all
+    unsigned long long pm = __ballot(piece);
+    if (pm) {
+        int leader = __ffsll((long long)pm) - 1;
+        uint32_t base = 0;
+        if (lane_id() == leader) base = atomicAdd(piece_count, (uint32_t)__popcll(pm));
+        base = __shfl(base, leader);
+        if (piece) piece_list[base + __popcll(pm & ((1ull << lane_id()) - 1ull))] = (uint32_t)r;
     }
     uint32_t len = hi - lo;
     if (len > 0 && len <= 32u)
@@ -213,7 +217,7 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 // One wave per mesh row (i,j,:) of the density.  The row receives mass from the particles of
 // the four mesh rows (i-di, j-dj), di,dj in {0,1}, through the corners (di,dj,0) into cell k and
 // (di,dj,1) into cell k+1 of their clouds (functions.py:56-68).  With the particles in cell
-// order each of those rows is one contiguous run of the particle arrays, found through
+// order each of those rows is one contiguous run of the particle array, found through
 // row_start.  The wave walks the four runs, 64 particles at a time, and adds the float64 corner
 // masses into a float64 copy of the row held in LDS; the row is rounded to float32 once, when
 // it is written out.  No global atomics, no mesh-sized index: the only mesh traffic is the one
@@ -221,51 +225,48 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 //
 // All adds to a row come from one wave, in program order, so the sum has one fixed order.
 // Two things keep dense clumps from serialising the walk:
-//  * heavy cells (more than HEAVY_CELL particles) are summed once, for all eight corners, by
-//    k_heavy_cells (one wave per piece of the cell's run, fixed butterfly); the walk then takes
-//    the cell's sums from pre[] at the cell's first particle and jumps over the rest;
+//  * the runs of heavy cells (more than HEAVY_CELL particles) are summed once, for all eight
+//    corners, by k_heavy_pieces (one wave per piece, fixed butterfly); the walk takes a piece's
+//    sums from pre[] at the piece's first particle and jumps over the rest of the piece;
 //  * rows still fed by more than HEAVY_ROW particles are left to k_deposit_heavy, where the
 //    waves of a block each walk a contiguous slice of the runs into their own LDS row and the
 //    slices are added in wave order.
 constexpr uint32_t HEAVY_ROW = 2048;
 
-// The eight corner masses of particle r: mass * wx * wy * wz, left to right (functions.py:61-68),
-// indexed q = di + 2*dj + 4*dk.
-template <typename TP>
-__device__ __forceinline__ void corner_masses(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
-                                              const float *__restrict__ m, uint32_t r, const pm_geom &g, double w[8])
-{
-    cell_t c = locate((double)x[r], (double)y[r], (double)z[r], g);
-    double mm = (double)m[r];
-    double mx[2] = {mm * (1.0 - c.dx), mm * c.dx};
-    double wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w[q] = mx[q & 1] * wy[(q >> 1) & 1] * wz[q >> 2];
-}
-
-// One wave per listed piece of a heavy cell's run: the eight corner sums of the piece go to
-// pre[q*cap + first particle of the cell + piece number]; skip[] gets, for every particle of the
-// piece, the index one past the cell's run (the cell's first particle also gets SKIP_HEAD).
+// One wave per listed piece.  The piece is the part of the run of its first particle's cell that
+// lies before the next multiple of HEAVY_PIECE.  Its eight corner sums (mass * wx * wy * wz, left
+// to right, functions.py:61-68; q = di + 2*dj + 4*dk) go to pre[q*cap + first]; skip[] gets, for
+// every particle of the piece, the index one past the piece (the first one also SKIP_HEAD).
 template <typename TP>
 __global__ void __launch_bounds__(BLOCK)
-k_heavy_cells(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z, const float *__restrict__ m,
-              const uint32_t *__restrict__ cell_list, const uint32_t *__restrict__ cell_count,
-              double *__restrict__ pre, uint32_t *__restrict__ skip, int64_t cap, pm_geom g)
+k_heavy_pieces(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ piece_list,
+               const uint32_t *__restrict__ piece_count, double *__restrict__ pre, uint32_t *__restrict__ skip,
+               int64_t n, int64_t cap, pm_geom g)
 {
-    const uint32_t cnt = *cell_count;
+    const uint32_t cnt = *piece_count;
     const uint32_t waves = gridDim.x * (BLOCK / 64);
     for (uint32_t e = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); e < cnt; e += waves) {
-        const uint32_t beg = cell_list[3 * e], end = cell_list[3 * e + 1], piece = cell_list[3 * e + 2];
-        const uint32_t pb = beg + piece * HEAVY_PIECE;
-        const uint32_t pe = (end - pb > HEAVY_PIECE) ? pb + HEAVY_PIECE : end;
+        const uint32_t first = piece_list[e];
+        const uint32_t k0 = key[first];
+        int64_t bound = ((int64_t)(first / HEAVY_PIECE) + 1) * HEAVY_PIECE;
+        if (bound > n) bound = n;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t r = pb + lane_id(); r < pe; r += 64) {
-            double w[8];
-            corner_masses(x, y, z, m, r, g, w);
+        uint32_t mine = 0;
+        for (int64_t r = (int64_t)first + lane_id(); r < bound; r += 64) {
+            if (key[r] != k0) break;                      // cell order: the run has ended
+            pm_prec<TP> p = P[r];
+            cell_t c = locate(p, g);
+            double mm = (double)p.m;
+            double mx[2] = {mm * (1.0 - c.dx), mm * c.dx};
+            double wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += w[q];
-            skip[r] = (r == beg) ? (end | SKIP_HEAD) : end;
+            for (int q = 0; q < 8; ++q) acc[q] += mx[q & 1] * wy[(q >> 1) & 1] * wz[q >> 2];
+            ++mine;
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+        const uint32_t end = first + mine;
+        for (uint32_t r = first + lane_id(); r < end; r += 64) skip[r] = (r == first) ? (end | SKIP_HEAD) : end;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -275,23 +276,9 @@ k_heavy_cells(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__re
             double v = acc[0];
 #pragma unroll
             for (int q = 1; q < 8; ++q) v = (lane_id() == q) ? acc[q] : v;
-            pre[(int64_t)lane_id() * cap + beg + piece] = v;
+            pre[(int64_t)lane_id() * cap + first] = v;
         }
     }
-}
-
-// Mass of particle r entering cells k (lo) and k+1 (hi) of the row displaced by (di,dj):
-// mass * wx * wy * wz, left to right (functions.py:61-68).
-template <typename TP>
-__device__ __forceinline__ void row_masses(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
-                                           const float *__restrict__ m, uint32_t r, int di, int dj, const pm_geom &g,
-                                           int &k, double &lo, double &hi)
-{
-    cell_t c = locate((double)x[r], (double)y[r], (double)z[r], g);
-    double w = (double)m[r] * (di ? c.dx : 1.0 - c.dx) * (dj ? c.dy : 1.0 - c.dy);
-    k = c.k;
-    lo = w * (1.0 - c.dz);
-    hi = w * c.dz;
 }
 
 __device__ __forceinline__ void lds_add(double *p, double v)
@@ -303,12 +290,11 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 // cell order, so the lanes of a pass hold non-decreasing k and the lanes that share a cell are
 // neighbours.  Where many lanes share cells their masses are first summed by a segmented scan
 // over the wave (fixed tree order) and only the last lane of every cell adds to LDS; otherwise
-// every lane adds its own.  Particles of a heavy cell are represented by the cell's first
-// particle alone, which adds the sums k_heavy_cells left in pre[]; when a pass ends inside a
-// heavy cell the walk continues after that cell.
+// every lane adds its own.  A piece of a heavy cell is represented by its first particle alone,
+// which adds the sums k_heavy_pieces left in pre[]; when a pass ends inside a piece the walk
+// continues after it.
 template <typename TP>
-__device__ __forceinline__ void deposit_run(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z,
-                                            const float *__restrict__ m, const uint32_t *__restrict__ key,
+__device__ __forceinline__ void deposit_run(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key,
                                             const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
                                             uint32_t beg, uint32_t end, int di, int dj, const pm_geom &g, double *acc)
 {
@@ -319,17 +305,20 @@ __device__ __forceinline__ void deposit_run(const TP *__restrict__ x, const TP *
     while (base < end) {                                        // wave-uniform
         const uint32_t r = base + lane;
         const bool live = r < end;
-        const uint32_t sk = live ? skip[r] : 0u;
+        uint32_t sk = 0u;
+        pm_prec<TP> p{};
+        if (live) { sk = skip[r]; p = P[r]; }                   // both loads in flight together
         int k = 0x7fffffff - lane;                              // idle lanes: distinct, never equal to a cell
         double lo = 0.0, hi = 0.0;
         bool add = false;
         if (live && sk == 0u) {
-            row_masses(x, y, z, m, r, di, dj, g, k, lo, hi);
+            cell_t c = locate(p, g);
+            double w = (double)p.m * (di ? c.dx : 1.0 - c.dx) * (dj ? c.dy : 1.0 - c.dy);
+            k = c.k; lo = w * (1.0 - c.dz); hi = w * c.dz;
             add = true;
         } else if (sk & SKIP_HEAD) {
-            const uint32_t cend = sk & ~SKIP_HEAD;
             k = (int)(key[r] % (uint32_t)G);
-            for (uint32_t p = r; p < r + (cend - r + HEAVY_PIECE - 1) / HEAVY_PIECE; ++p) { lo += pre_lo[p]; hi += pre_hi[p]; }
+            lo = pre_lo[r]; hi = pre_hi[r];
             add = true;
         }
         int kprev = __shfl_up(k, 1);
@@ -348,7 +337,7 @@ __device__ __forceinline__ void deposit_run(const TP *__restrict__ x, const TP *
             lds_add(&acc[k], lo);
             lds_add(&acc[(k + 1 == G) ? 0 : k + 1], hi);
         }
-        const uint32_t sk_last = __shfl(sk, 63) & ~SKIP_HEAD;   // 0 unless the pass ended inside a heavy cell
+        const uint32_t sk_last = __shfl(sk, 63) & ~SKIP_HEAD;   // 0 unless the pass ended inside a piece
         base = (sk_last != 0u) ? sk_last : base + 64;
     }
 }
@@ -373,10 +362,9 @@ __device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uin
 
 template <typename TP>
 __global__ void __launch_bounds__(BLOCK)
-k_deposit_rows(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z, const float *__restrict__ m,
-               const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
-               const uint32_t *__restrict__ rs, float *__restrict__ density, uint32_t *__restrict__ heavy_rows,
-               uint32_t *__restrict__ heavy_count, pm_geom g)
+k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
+               const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
+               uint32_t *__restrict__ heavy_rows, uint32_t *__restrict__ heavy_count, pm_geom g)
 {
     extern __shared__ double lds_rows[];
     const int G = g.G;
@@ -395,19 +383,18 @@ k_deposit_rows(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__r
         return;
     }
     for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
-    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[0], t.end[0], 0, 0, g, acc);
-    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[1], t.end[1], 1, 0, g, acc);
-    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[2], t.end[2], 0, 1, g, acc);
-    deposit_run(x, y, z, m, key, skip, pre, cap, t.beg[3], t.end[3], 1, 1, g, acc);
+    deposit_run(P, key, skip, pre, cap, t.beg[0], t.end[0], 0, 0, g, acc);
+    deposit_run(P, key, skip, pre, cap, t.beg[1], t.end[1], 1, 0, g, acc);
+    deposit_run(P, key, skip, pre, cap, t.beg[2], t.end[2], 0, 1, g, acc);
+    deposit_run(P, key, skip, pre, cap, t.beg[3], t.end[3], 1, 1, g, acc);
     for (int c = lane_id(); c < G; c += 64) out[c] = (float)acc[c];
 }
 
 template <typename TP>
 __global__ void __launch_bounds__(1024)
-k_deposit_heavy(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__restrict__ z, const float *__restrict__ m,
-                const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
-                const uint32_t *__restrict__ rs, float *__restrict__ density, const uint32_t *__restrict__ heavy_rows,
-                const uint32_t *__restrict__ heavy_count, pm_geom g)
+k_deposit_heavy(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
+                const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
+                const uint32_t *__restrict__ heavy_rows, const uint32_t *__restrict__ heavy_count, pm_geom g)
 {
     extern __shared__ double lds_rows[];
     const int G = g.G;
@@ -426,7 +413,7 @@ k_deposit_heavy(const TP *__restrict__ x, const TP *__restrict__ y, const TP *__
             uint32_t b = t.beg[q] + (uint32_t)w * sl, e2 = b + sl;
             if (b > t.end[q]) b = t.end[q];
             if (e2 > t.end[q]) e2 = t.end[q];
-            deposit_run(x, y, z, m, key, skip, pre, cap, b, e2, q & 1, q >> 1, g, acc);
+            deposit_run(P, key, skip, pre, cap, b, e2, q & 1, q >> 1, g, acc);
         }
         __syncthreads();
         float *out = density + (size_t)row * G;
@@ -450,95 +437,135 @@ __device__ __forceinline__ float diff1(const float *__restrict__ f, int64_t q, i
     return (f[q + stride] - f[q - stride]) * 0.5f;
 }
 
+// 4-byte-aligned runs of 2 and 4 floats along a mesh row
+struct __attribute__((packed, aligned(4))) f2u { float v[2]; };
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+
+// corner order of functions.py:61-68 and :140-178: 000 100 010 001 110 101 011 111
+__device__ constexpr int DI[8] = {0, 1, 0, 0, 1, 1, 0, 1}, DJ[8] = {0, 0, 1, 0, 1, 0, 1, 1}, DK[8] = {0, 0, 0, 1, 0, 1, 1, 1};
+
 template <typename TP, typename TV, bool FUSED>
 __global__ void __launch_bounds__(BLOCK)
-k_gather(const TP *__restrict__ px, const TP *__restrict__ py, const TP *__restrict__ pz,
-         float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz,
-         TV *__restrict__ vx, TV *__restrict__ vy, TV *__restrict__ vz,
+k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, pm_vrec<TV> *__restrict__ V,
          const float *__restrict__ gx, const float *__restrict__ gy, const float *__restrict__ gz,
          const float *__restrict__ phi, float *__restrict__ forces, int64_t n, pm_geom g, double dt, bool integrate)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
     const int G = g.G;
-    double x = (double)px[r], y = (double)py[r], z = (double)pz[r];
-    cell_t c = locate(x, y, z, g);
-    int i1 = (c.i + 1 == G) ? 0 : c.i + 1, j1 = (c.j + 1 == G) ? 0 : c.j + 1, k1 = (c.k + 1 == G) ? 0 : c.k + 1;
-    double wx[2] = {1.0 - c.dx, c.dx}, wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
-    int ii[2] = {c.i, i1}, jj[2] = {c.j, j1}, kk[2] = {c.k, k1};
+    const pm_prec<TP> p = Pin[r];
+    const cell_t c = locate(p, g);
+    const int i1 = (c.i + 1 == G) ? 0 : c.i + 1, j1 = (c.j + 1 == G) ? 0 : c.j + 1, k1 = (c.k + 1 == G) ? 0 : c.k + 1;
+    const double wx[2] = {1.0 - c.dx, c.dx}, wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
+    const int ii[2] = {c.i, i1}, jj[2] = {c.j, j1}, kk[2] = {c.k, k1};
+    float ga[2][2][2], gb[2][2][2], gc[2][2][2];        // gradient components at corner [di][dj][dk]
+    const int64_t s0 = (int64_t)G * G, s1 = G;
+    if (FUSED) {
+        // np.gradient of the potential, evaluated at the eight corners on the fly
+        const bool inner = c.i >= 1 && c.i <= G - 3 && c.j >= 1 && c.j <= G - 3 && c.k >= 1 && c.k <= G - 3;
+        if (inner) {
+            // all eight corners are interior nodes and nothing wraps: 4 + 4 + 4 short row segments
+            const float *b = phi + ((int64_t)c.i * G + c.j) * G + c.k;
+            f4u ctr[2][2];                                  // phi(i+a, j+b, k-1 .. k+2)
+            f2u xm[2], xp[2], ym[2], yp[2];                 // phi(i-1 | i+2, j+b, k .. k+1), phi(i+a, j-1 | j+2, k .. k+1)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) ctr[a][bb] = *(const f4u *)(b + a * s0 + bb * s1 - 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                xm[q] = *(const f2u *)(b - s0 + q * s1);
+                xp[q] = *(const f2u *)(b + 2 * s0 + q * s1);
+                ym[q] = *(const f2u *)(b + q * s0 - s1);
+                yp[q] = *(const f2u *)(b + q * s0 + 2 * s1);
+            }
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    ga[0][bb][cc] = (ctr[1][bb].v[1 + cc] - xm[bb].v[cc]) * 0.5f;
+                    ga[1][bb][cc] = (xp[bb].v[cc] - ctr[0][bb].v[1 + cc]) * 0.5f;
+                    gb[bb][0][cc] = (ctr[bb][1].v[1 + cc] - ym[bb].v[cc]) * 0.5f;
+                    gb[bb][1][cc] = (yp[bb].v[cc] - ctr[bb][0].v[1 + cc]) * 0.5f;
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    gc[a][bb][0] = (ctr[a][bb].v[2] - ctr[a][bb].v[0]) * 0.5f;
+                    gc[a][bb][1] = (ctr[a][bb].v[3] - ctr[a][bb].v[1]) * 0.5f;
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int a = ii[DI[q]], b = jj[DJ[q]], cc = kk[DK[q]];
+                int64_t node = ((int64_t)a * G + b) * G + cc;
+                ga[DI[q]][DJ[q]][DK[q]] = diff1(phi, node, s0, a, G);
+                gb[DI[q]][DJ[q]][DK[q]] = diff1(phi, node, s1, b, G);
+                gc[DI[q]][DJ[q]][DK[q]] = diff1(phi, node, 1, cc, G);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int64_t node = ((int64_t)ii[DI[q]] * G + jj[DJ[q]]) * G + kk[DK[q]];
+            ga[DI[q]][DJ[q]][DK[q]] = gx[node]; gb[DI[q]][DJ[q]][DK[q]] = gy[node]; gc[DI[q]][DJ[q]][DK[q]] = gz[node];
+        }
+    }
+    // functions.py:140-178: every add rounds the float32 accumulator
     float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-    // corner order of functions.py:140-178; each add rounds the float32 accumulator
-    constexpr int DI[8] = {0, 1, 0, 0, 1, 1, 0, 1}, DJ[8] = {0, 0, 1, 0, 1, 0, 1, 1}, DK[8] = {0, 0, 0, 1, 0, 1, 1, 1};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        int a = ii[DI[q]], b = jj[DJ[q]], cc = kk[DK[q]];
-        int64_t node = ((int64_t)a * G + b) * G + cc;
         double w = wx[DI[q]] * wy[DJ[q]] * wz[DK[q]];
-        float ga, gb, gc;
-        if (FUSED) {
-            ga = diff1(phi, node, (int64_t)G * G, a, G);
-            gb = diff1(phi, node, G, b, G);
-            gc = diff1(phi, node, 1, cc, G);
-        } else {
-            ga = gx[node]; gb = gy[node]; gc = gz[node];
-        }
-        fx = (float)((double)fx + (double)ga * w);
-        fy = (float)((double)fy + (double)gb * w);
-        fz = (float)((double)fz + (double)gc * w);
+        fx = (float)((double)fx + (double)ga[DI[q]][DJ[q]][DK[q]] * w);
+        fy = (float)((double)fy + (double)gb[DI[q]][DJ[q]][DK[q]] * w);
+        fz = (float)((double)fz + (double)gc[DI[q]][DJ[q]][DK[q]] * w);
     }
     if (forces) { forces[3 * r] = fx; forces[3 * r + 1] = fy; forces[3 * r + 2] = fz; }
     if (!integrate) return;
     // main.py:58-60
     const float dtf = (float)dt;
     float dvx = fx * dtf, dvy = fy * dtf, dvz = fz * dtf;      // float32 product (weak Python float)
+    pm_vrec<TV> v = V[r];
     // velocities += forces*dt : the add runs in the velocities' dtype
-    TV ux, uy, uz;
-    if constexpr (sizeof(TV) == 4) { ux = vx[r] + dvx; uy = vy[r] + dvy; uz = vz[r] + dvz; }
-    else { ux = vx[r] + (double)dvx; uy = vy[r] + (double)dvy; uz = vz[r] + (double)dvz; }
-    vx[r] = ux; vy[r] = uy; vz[r] = uz;
+    if constexpr (sizeof(TV) == 4) { v.x = v.x + dvx; v.y = v.y + dvy; v.z = v.z + dvz; }
+    else { v.x = v.x + (double)dvx; v.y = v.y + (double)dvy; v.z = v.z + (double)dvz; }
+    V[r] = v;
     // positions += velocities*dt : float32 product for float32 velocities, the add in the wider
     // of the two dtypes, the result cast to float32 (on store, or by .astype at main.py:60)
+    pm_prec<float> o;
+    o.m = p.m;
     if constexpr (sizeof(TV) == 4 && sizeof(TP) == 4) {
-        ox[r] = wrap_f32(px[r] + ux * dtf, g.Lf);
-        oy[r] = wrap_f32(py[r] + uy * dtf, g.Lf);
-        oz[r] = wrap_f32(pz[r] + uz * dtf, g.Lf);
+        o.x = wrap_f32(p.x + v.x * dtf, g.Lf);
+        o.y = wrap_f32(p.y + v.y * dtf, g.Lf);
+        o.z = wrap_f32(p.z + v.z * dtf, g.Lf);
     } else {
         double mx, my, mz;
-        if constexpr (sizeof(TV) == 4) { mx = (double)(ux * dtf); my = (double)(uy * dtf); mz = (double)(uz * dtf); }
-        else { mx = ux * dt; my = uy * dt; mz = uz * dt; }
-        ox[r] = wrap_f32((float)(x + mx), g.Lf);
-        oy[r] = wrap_f32((float)(y + my), g.Lf);
-        oz[r] = wrap_f32((float)(z + mz), g.Lf);
+        if constexpr (sizeof(TV) == 4) { mx = (double)(v.x * dtf); my = (double)(v.y * dtf); mz = (double)(v.z * dtf); }
+        else { mx = v.x * dt; my = v.y * dt; mz = v.z * dt; }
+        o.x = wrap_f32((float)((double)p.x + mx), g.Lf);
+        o.y = wrap_f32((float)((double)p.y + my), g.Lf);
+        o.z = wrap_f32((float)((double)p.z + mz), g.Lf);
     }
+    Pout[r] = o;
 }
-
-inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
 
 }  // namespace
 
 // ---- launchers -----------------------------------------------------------------------------
 
-hipError_t pm_launch_aos_to_soa(pm_ctx *c, const void *aos, bool f64, void *const dst[3], int64_t n)
+hipError_t pm_launch_pack(pm_ctx *c, const void *pos_aos, const float *mass, const void *vel_aos)
 {
+    const int64_t n = c->n;
     if (n == 0) return hipSuccess;
-    if (f64)
-        k_aos_to_soa<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>((const double *)aos, (double *)dst[0], (double *)dst[1], (double *)dst[2], n);
-    else
-        k_aos_to_soa<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>((const float *)aos, (float *)dst[0], (float *)dst[1], (float *)dst[2], n);
-    return hipGetLastError();
-}
-
-hipError_t pm_launch_fill_particles_defaults(pm_ctx *c, bool zero_vel, bool ones_mass)
-{
-    int64_t n = c->n;
-    if (n == 0) return hipSuccess;
-    k_iota<<<grid_for(n), BLOCK, 0, c->stream>>>(c->id[c->cur], n);
-    if (ones_mass) k_fill<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->m[c->cur], 1.0f, n);
-    if (zero_vel)
-        for (int a = 0; a < 3; ++a) {
-            if (c->vel_f64) k_fill<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vd[c->cur][a], 0.0, n);
-            else k_fill<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vf[c->cur][a], 0.0f, n);
-        }
+    const int u = c->cur;
+    if (pos_aos) {
+        if (c->pos_f64) k_pack_pos<double><<<grid_for(n), BLOCK, 0, c->stream>>>((const double *)pos_aos, mass, c->pd[u], n);
+        else k_pack_pos<float><<<grid_for(n), BLOCK, 0, c->stream>>>((const float *)pos_aos, mass, c->pf[u], n);
+    } else {
+        if (c->vel_f64) k_pack_vel<double><<<grid_for(n), BLOCK, 0, c->stream>>>((const double *)vel_aos, c->vd[u], n);
+        else k_pack_vel<float><<<grid_for(n), BLOCK, 0, c->stream>>>((const float *)vel_aos, c->vf[u], n);
+    }
     return hipGetLastError();
 }
 
@@ -547,10 +574,8 @@ hipError_t pm_launch_cell_keys(pm_ctx *c)
     int64_t n = c->n;
     if (n == 0) return hipSuccess;
     int u = c->cur;
-    if (c->pos_f64)
-        k_cell_keys<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->xd[u][0], c->xd[u][1], c->xd[u][2], c->key_in, n, c->g);
-    else
-        k_cell_keys<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->x[u][0], c->x[u][1], c->x[u][2], c->key_in, n, c->g);
+    if (c->pos_f64) k_cell_keys<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->key_in, n, c->g);
+    else k_cell_keys<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->key_in, n, c->g);
     return hipGetLastError();
 }
 
@@ -559,17 +584,13 @@ hipError_t pm_launch_reorder(pm_ctx *c)
     int64_t n = c->n;
     if (n == 0) return hipSuccess;
     int u = c->cur, w = 1 - u;
-    reorder_args a{};
-    for (int d = 0; d < 3; ++d) {
-        a.x_in[d] = c->x[u][d]; a.x_out[d] = c->x[w][d];
-        a.xd_in[d] = c->xd[u][d]; a.xd_out[d] = c->xd[w][d];
-        a.vf_in[d] = c->vf[u][d]; a.vf_out[d] = c->vf[w][d];
-        a.vd_in[d] = c->vd[u][d]; a.vd_out[d] = c->vd[w][d];
+    if (c->pos_f64) {
+        if (c->vel_f64) k_reorder<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vd[u], c->vd[w], c->src, n);
+        else k_reorder<double, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vf[u], c->vf[w], c->src, n);
+    } else {
+        if (c->vel_f64) k_reorder<float, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vd[u], c->vd[w], c->src, n);
+        else k_reorder<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vf[u], c->vf[w], c->src, n);
     }
-    a.m_in = c->m[u]; a.m_out = c->m[w];
-    a.id_in = c->id[u]; a.id_out = c->id[w];
-    a.src = c->src; a.n = n; a.pos_f64 = c->pos_f64; a.vel_f64 = c->vel_f64;
-    k_reorder<<<grid_for(n), BLOCK, 0, c->stream>>>(a);
     c->cur = w;
     return hipGetLastError();
 }
@@ -577,31 +598,30 @@ hipError_t pm_launch_reorder(pm_ctx *c)
 hipError_t pm_launch_row_start(pm_ctx *c)
 {
     const uint32_t G = (uint32_t)c->g.G;
-    hipError_t e = hipMemsetAsync(c->heavy_count, 0, 2 * sizeof(uint32_t), c->stream);     // [0] heavy rows, [1] heavy-cell pieces
+    hipError_t e = hipMemsetAsync(c->counters, 0, 2 * sizeof(uint32_t), c->stream);
     if (e != hipSuccess) return e;
-    k_row_start<<<grid_for(c->n + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, G, G * G, c->row_start, c->skip, c->cell_list, c->heavy_count + 1);
+    k_row_start<<<grid_for(c->n + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, G, G * G, c->row_start, c->skip, c->piece_list, c->counters + 1);
     return hipGetLastError();
 }
 
-int pm_heavy_waves(int G)
+static int heavy_waves(int G)
 {
     int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double)));
     return nw > 16 ? 16 : (nw < 1 ? 1 : nw);
 }
 
 template <typename TP>
-static hipError_t deposit_dispatch(pm_ctx *c, const TP *const p[3])
+static hipError_t deposit_dispatch(pm_ctx *c, const pm_prec<TP> *P)
 {
     const int G = c->g.G;
     const uint32_t R = (uint32_t)G * (uint32_t)G;
-    const int u = c->cur;
-    hipError_t e = hipMemsetAsync(c->heavy_count, 0, sizeof(uint32_t), c->stream);
+    hipError_t e = hipMemsetAsync(c->counters, 0, sizeof(uint32_t), c->stream);     // heavy rows; the piece count stays
     if (e != hipSuccess) return e;
-    k_heavy_cells<TP><<<1024, BLOCK, 0, c->stream>>>(p[0], p[1], p[2], c->m[u], c->cell_list, c->heavy_count + 1, c->pre, c->skip, c->cap, c->g);
+    k_heavy_pieces<TP><<<1024, BLOCK, 0, c->stream>>>(P, c->key_out, c->piece_list, c->counters + 1, c->pre, c->skip, c->n, c->cap, c->g);
     const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double);
     k_deposit_rows<TP><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
-        p[0], p[1], p[2], c->m[u], c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->heavy_rows, c->heavy_count, c->g);
-    const int nw = pm_heavy_waves(G);
+        P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->heavy_rows, c->counters, c->g);
+    const int nw = heavy_waves(G);
     const size_t lds_heavy = (size_t)nw * G * sizeof(double);
     static bool attr_set[2] = {false, false};
     if (!attr_set[sizeof(TP) == 8]) {
@@ -609,29 +629,27 @@ static hipError_t deposit_dispatch(pm_ctx *c, const TP *const p[3])
         if (e != hipSuccess) return e;
         attr_set[sizeof(TP) == 8] = true;
     }
-    k_deposit_heavy<TP><<<512, nw * 64, lds_heavy, c->stream>>>(p[0], p[1], p[2], c->m[u], c->key_out, c->skip, c->pre, c->cap,
-                                                                c->row_start, c->density, c->heavy_rows, c->heavy_count, c->g);
+    k_deposit_heavy<TP><<<512, nw * 64, lds_heavy, c->stream>>>(P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density,
+                                                                c->heavy_rows, c->counters, c->g);
     return hipGetLastError();
 }
 
 hipError_t pm_launch_deposit(pm_ctx *c)
 {
     int u = c->cur;
-    if (c->pos_f64) return deposit_dispatch<double>(c, c->xd[u]);
-    return deposit_dispatch<float>(c, c->x[u]);
+    if (c->pos_f64) return deposit_dispatch<double>(c, c->pd[u]);
+    return deposit_dispatch<float>(c, c->pf[u]);
 }
 
 template <typename TP, typename TV>
-static void gather_dispatch(pm_ctx *c, const TP *const p[3], TV *const v[3], double dt, bool integrate, float *forces, bool fused)
+static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *V, double dt, bool integrate, float *forces, bool fused)
 {
-    int u = c->cur;
     int64_t n = c->n;
+    pm_prec<float> *out = c->pf[c->cur];
     if (fused)
-        k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(p[0], p[1], p[2], c->x[u][0], c->x[u][1], c->x[u][2], v[0], v[1], v[2],
-                                                                     nullptr, nullptr, nullptr, c->potential, forces, n, c->g, dt, integrate);
+        k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, nullptr, nullptr, nullptr, c->potential, forces, n, c->g, dt, integrate);
     else
-        k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(p[0], p[1], p[2], c->x[u][0], c->x[u][1], c->x[u][2], v[0], v[1], v[2],
-                                                                      c->grad[0], c->grad[1], c->grad[2], nullptr, forces, n, c->g, dt, integrate);
+        k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, n, c->g, dt, integrate);
 }
 
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient)
@@ -640,31 +658,32 @@ hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_for
     int u = c->cur;
     float *f = store_forces ? c->forces : nullptr;
     if (c->pos_f64) {
-        if (c->vel_f64) gather_dispatch<double, double>(c, c->xd[u], c->vd[u], dt, integrate, f, fused_gradient);
-        else gather_dispatch<double, float>(c, c->xd[u], c->vf[u], dt, integrate, f, fused_gradient);
+        if (c->vel_f64) gather_dispatch<double, double>(c, c->pd[u], c->vd[u], dt, integrate, f, fused_gradient);
+        else gather_dispatch<double, float>(c, c->pd[u], c->vf[u], dt, integrate, f, fused_gradient);
     } else {
-        if (c->vel_f64) gather_dispatch<float, double>(c, c->x[u], c->vd[u], dt, integrate, f, fused_gradient);
-        else gather_dispatch<float, float>(c, c->x[u], c->vf[u], dt, integrate, f, fused_gradient);
+        if (c->vel_f64) gather_dispatch<float, double>(c, c->pf[u], c->vd[u], dt, integrate, f, fused_gradient);
+        else gather_dispatch<float, float>(c, c->pf[u], c->vf[u], dt, integrate, f, fused_gradient);
     }
     return hipGetLastError();
 }
 
-hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, bool pos_f64, void *vel_aos)
+hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos)
 {
     int64_t n = c->n;
     if (n == 0) return hipSuccess;
     int u = c->cur;
     if (pos_aos) {
-        if (pos_f64)
-            k_soa_to_aos_by_id<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->xd[u][0], c->xd[u][1], c->xd[u][2], c->id[u], (double *)pos_aos, n);
-        else
-            k_soa_to_aos_by_id<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->x[u][0], c->x[u][1], c->x[u][2], c->id[u], (float *)pos_aos, n);
+        if (c->pos_f64) {
+            if (c->vel_f64) k_export_pos<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->vd[u], (double *)pos_aos, n);
+            else k_export_pos<double, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->vf[u], (double *)pos_aos, n);
+        } else {
+            if (c->vel_f64) k_export_pos<float, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->vd[u], (float *)pos_aos, n);
+            else k_export_pos<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->vf[u], (float *)pos_aos, n);
+        }
     }
     if (vel_aos) {
-        if (c->vel_f64)
-            k_soa_to_aos_by_id<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vd[u][0], c->vd[u][1], c->vd[u][2], c->id[u], (double *)vel_aos, n);
-        else
-            k_soa_to_aos_by_id<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vf[u][0], c->vf[u][1], c->vf[u][2], c->id[u], (float *)vel_aos, n);
+        if (c->vel_f64) k_export_vel<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vd[u], (double *)vel_aos, n);
+        else k_export_vel<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vf[u], (float *)vel_aos, n);
     }
     return hipGetLastError();
 }
@@ -672,13 +691,15 @@ hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, bool pos_f64, vo
 hipError_t pm_launch_export_forces(pm_ctx *c, float *aos)
 {
     if (c->n == 0) return hipSuccess;
-    k_aos_by_id<<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->id[c->cur], aos, c->n);
+    if (c->vel_f64) k_export_forces<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vd[c->cur], aos, c->n);
+    else k_export_forces<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vf[c->cur], aos, c->n);
     return hipGetLastError();
 }
 
 hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
 {
     if (c->n == 0) return hipSuccess;
-    k_export_keys<<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->id[c->cur], keys, perm, c->n);
+    if (c->vel_f64) k_export_keys<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vd[c->cur], keys, perm, c->n);
+    else k_export_keys<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vf[c->cur], keys, perm, c->n);
     return hipGetLastError();
 }
