@@ -88,7 +88,8 @@ int ensure_binned(pm_ctx *c)
 {
     if (c->binned) return PM_OK;
     stage_timer t(c, PM_STAGE_BIN);
-    HIP_TRY(c, pm_launch_cell_keys(c));
+    if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
+    c->keys_fresh = false;      // the sort consumes key_in
     HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
     HIP_TRY(c, pm_launch_reorder(c));
     HIP_TRY(c, pm_launch_row_start(c));
@@ -147,9 +148,9 @@ static int create_impl(pm_ctx *c)
     c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, (size_t)G * G + 1));
-    TRY(dalloc(c, &c->heavy_rows, (size_t)G * G));
-    TRY(dalloc(c, &c->counters, 2));
-    TRY(dalloc(c, &c->piece_list, cap / 64 + cap / 2048 + 2));
+    TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G)));
+    TRY(dalloc(c, &c->counters, PM_NUM_COUNTERS));
+    TRY(dalloc(c, &c->piece_list, pm_piece_list_entries(c->cap)));
     TRY(dalloc(c, &c->skip, cap));
     TRY(dalloc(c, &c->pre, 8 * cap));
     TRY(dalloc(c, &c->density, M));
@@ -242,7 +243,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     c->pos_in_f64 = c->pos_f64 = (pos_dtype == PM_F64);
     c->vel_f64 = (vel_dtype == PM_F64);
     TRY(alloc_particles(c));
-    c->n = n; c->cur = 0; c->binned = false; c->have_forces = false;
+    c->n = n; c->cur = 0; c->binned = false; c->have_forces = false; c->keys_fresh = false;
     size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
     if (n > 0) {
         // staging: positions (n,3), then the masses behind them
@@ -319,6 +320,7 @@ static int gather_kick_drift(pm_ctx *c, double dt, bool fused)
     c->pos_f64 = false;      // positions are float32 from the first drift on (main.py:60)
     c->binned = false;
     c->have_forces = false;
+    c->keys_fresh = true;
     return PM_OK;
 }
 

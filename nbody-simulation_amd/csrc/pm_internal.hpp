@@ -53,6 +53,7 @@ struct pm_ctx {
     bool vel_f64 = false;
     bool binned = false;        // live set is in cell order and row_start matches it
     bool have_forces = false;
+    bool keys_fresh = false;    // key_in holds the cell keys of the live positions (written by the last drift)
 
     // binning scratch
     uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;
@@ -60,7 +61,7 @@ struct pm_ctx {
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
     uint32_t *heavy_rows = nullptr;     // density rows fed by more particles than one wave should walk
-    uint32_t *counters = nullptr;       // [0] heavy rows listed, [1] heavy-cell pieces listed
+    uint32_t *counters = nullptr;       // sharded list counters: heavy rows, then heavy-cell pieces (PM_NUM_COUNTERS words)
     uint32_t *piece_list = nullptr;     // first particle of every piece of a heavy cell's run
     uint32_t *skip = nullptr;           // per particle: 0, or one past its piece of a heavy cell (+ head bit)
     double *pre = nullptr;              // [8][cap]: corner sums of a piece, at the piece's first particle
@@ -85,6 +86,12 @@ struct pm_ctx {
 
     std::string err;
 };
+
+// counters[]: 16 heavy-row shards then 64 piece shards, one counter per 32 words (its own 128-byte line)
+constexpr int PM_PIECE_COUNTERS = 16 * 32, PM_NUM_COUNTERS = (16 + 64) * 32;
+uint32_t pm_piece_shard_cap(int64_t cap);
+size_t pm_piece_list_entries(int64_t cap);
+size_t pm_heavy_row_entries(int G);
 
 // ---- launchers (each enqueues on ctx->stream and returns a hipError_t) ----------------------
 // stage -> records: positions (n,3) of the given dtype + masses (or ones), velocities (or zeros) + iota ids

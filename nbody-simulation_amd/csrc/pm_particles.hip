@@ -142,74 +142,74 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
     key[p] = (uint32_t)(((int64_t)c.i * g.G + c.j) * g.G + c.k);
 }
 
+// Cell order -> storage order.  Slot r of the new storage takes the records of old slot src[r].
+//
+// The same pass prepares the deposit's handling of "heavy" cells (more than HEAVY_CELL
+// particles): it clears skip[] and cuts the runs of heavy cells into pieces for k_heavy_pieces.
+// A piece starts at the first particle of a heavy cell, and at every multiple of HEAVY_PIECE that
+// has at least HEAVY_CELL particles of the same cell on either side (key[] is the sorted key
+// array, so slot r reads its neighbours' keys).
+constexpr uint32_t HEAVY_CELL = 16, HEAVY_PIECE = 2048;
+// Lists filled through atomic counters are split into shards, each with its own counter on its own
+// 128-byte line and its own region of the list, so that appends do not queue on one address.
+constexpr uint32_t PIECE_SHARDS = 64, ROW_SHARDS = 16, COUNTER_STRIDE = 32;
+// pieces a block of BLOCK consecutive particles can start: one per HEAVY_CELL + 1 particles, plus a cut
+constexpr uint32_t PIECES_PER_BLOCK = BLOCK / (HEAVY_CELL + 1) + 2;
+constexpr uint32_t SKIP_HEAD = 0x80000000u;
+
+// Is index c (a multiple of HEAVY_PIECE, inside a run of key k) the start of a new piece?
+__device__ __forceinline__ bool piece_cut(const uint32_t *__restrict__ key, int64_t c, uint32_t k, int64_t n)
+{
+    return c >= HEAVY_CELL && c + HEAVY_CELL - 1 < n && key[c - HEAVY_CELL] == k && key[c + HEAVY_CELL - 1] == k;
+}
+
 template <typename TP, typename TV>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
                           const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__restrict__ Vout,
-                          const uint32_t *__restrict__ src, int64_t n)
+                          const uint32_t *__restrict__ src, const uint32_t *__restrict__ key, uint32_t *__restrict__ skip,
+                          uint32_t *__restrict__ piece_list, uint32_t *__restrict__ piece_count, uint32_t shard_cap, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= n) return;
-    int64_t s = src[r];
-    Pout[r] = Pin[s];
-    Vout[r] = Vin[s];
+    bool piece = false;
+    if (r < n) {
+        int64_t s = src[r];
+        Pout[r] = Pin[s];
+        Vout[r] = Vin[s];
+        skip[r] = 0u;
+        uint32_t kcur = key[r];
+        bool head = (r == 0) || key[r - 1] != kcur;
+        if (head) {
+            piece = (r + HEAVY_CELL < n) && key[r + HEAVY_CELL] == kcur;      // run longer than HEAVY_CELL
+        } else if (r % HEAVY_PIECE == 0) {
+            piece = piece_cut(key, r, kcur, n);
+        }
+    }
+    // one atomic per wave, on the counter of this block's shard (a shard holds at most
+    // PIECES_PER_BLOCK entries per block that feeds it: shard_cap)
+    unsigned long long pm = __ballot(piece);
+    if (pm) {
+        const uint32_t shard = blockIdx.x % PIECE_SHARDS;
+        int leader = __ffsll((long long)pm) - 1;
+        uint32_t base = 0;
+        if (lane_id() == leader) base = atomicAdd(piece_count + shard * COUNTER_STRIDE, (uint32_t)__popcll(pm));
+        base = __shfl(base, leader);
+        if (piece) piece_list[(size_t)shard * shard_cap + base + __popcll(pm & ((1ull << lane_id()) - 1ull))] = (uint32_t)r;
+    }
 }
 
 // row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
-// [0, G*G]: thread r (0..n) owns the rows in (row(key[r-1]), row(key[r])].  Short runs of empty
-// rows are written by the owning lane, longer ones by its wave.
-//
-// The same pass cuts the runs of "heavy" cells (more than HEAVY_CELL particles) into pieces for
-// k_heavy_pieces: a piece starts at the cell's first particle and at every multiple of
-// HEAVY_PIECE inside the run.  It also clears skip[] (k_heavy_pieces then marks the particles of
-// heavy cells in it).
-constexpr uint32_t HEAVY_CELL = 64, HEAVY_PIECE = 2048;
-constexpr uint32_t SKIP_HEAD = 0x80000000u;
-
-__global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs,
-                            uint32_t *__restrict__ skip, uint32_t *__restrict__ piece_list, uint32_t *__restrict__ piece_count)
+// [0, G*G]: one bisection of the sorted keys per row.
+__global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs)
 {
-    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    uint32_t lo = 0, hi = 0;
-    bool piece = false;
-    if (r <= n) {
-        uint32_t kprev = (r == 0) ? 0u : key[r - 1];
-        uint32_t kcur = (r == n) ? 0u : key[r];
-        lo = (r == 0) ? 0u : kprev / G + 1u;
-        hi = (r == n) ? R + 1u : kcur / G + 1u;
-        if (r < n) {
-            skip[r] = 0u;
-            bool head = (r == 0) || kprev != kcur;
-            if (head) {
-                piece = (r + HEAVY_CELL < n) && key[r + HEAVY_CELL] == kcur;      // run longer than HEAVY_CELL
-            } else if (r % HEAVY_PIECE == 0) {
-                // a cut inside a run: the run is heavy iff it has more than HEAVY_CELL members; count up to
-                // HEAVY_CELL + 1 of them around the cut
-                uint32_t cnt = 0;
-                for (int64_t q = r - 1; q >= 0 && cnt <= HEAVY_CELL && key[q] == kcur; --q) ++cnt;
-                for (int64_t q = r; q < n && cnt <= HEAVY_CELL && key[q] == kcur; ++q) ++cnt;
-                piece = cnt > HEAVY_CELL;
-            }
-        }
+    uint32_t row = blockIdx.x * BLOCK + threadIdx.x;
+    if (row > R) return;
+    const uint64_t target = (uint64_t)row * G;          // first key of the row
+    int64_t lo = 0, hi = n;                             // first index in [lo, hi] with key >= target
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)key[mid] < target) lo = mid + 1; else hi = mid;
     }
-    // one atomic per wave: at most n / HEAVY_CELL + n / HEAVY_PIECE pieces in all
-    unsigned long long pm = __ballot(piece);
-    if (pm) {
-        int leader = __ffsll((long long)pm) - 1;
-        uint32_t base = 0;
-        if (lane_id() == leader) base = atomicAdd(piece_count, (uint32_t)__popcll(pm));
-        base = __shfl(base, leader);
-        if (piece) piece_list[base + __popcll(pm & ((1ull << lane_id()) - 1ull))] = (uint32_t)r;
-    }
-    uint32_t len = hi - lo;
-    if (len > 0 && len <= 32u)
-        for (uint32_t c = lo; c < hi; ++c) rs[c] = (uint32_t)r;
-    unsigned long long big = __ballot(len > 32u);
-    while (big) {
-        int l = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        uint32_t a = __shfl(lo, l), b = __shfl(hi, l), v = (uint32_t)__shfl(r, l);
-        for (uint32_t c = a + lane_id(); c < b; c += 64) rs[c] = v;
-    }
+    rs[row] = (uint32_t)lo;
 }
 
 // ---- CIC deposit ---------------------------------------------------------------------------
@@ -218,38 +218,44 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 // the four mesh rows (i-di, j-dj), di,dj in {0,1}, through the corners (di,dj,0) into cell k and
 // (di,dj,1) into cell k+1 of their clouds (functions.py:56-68).  With the particles in cell
 // order each of those rows is one contiguous run of the particle array, found through
-// row_start.  The wave walks the four runs, 64 particles at a time, and adds the float64 corner
+// row_start.  A wave walks the four runs, 64 particles at a time, and adds the float64 corner
 // masses into a float64 copy of the row held in LDS; the row is rounded to float32 once, when
 // it is written out.  No global atomics, no mesh-sized index: the only mesh traffic is the one
 // coalesced write of the density.
 //
-// All adds to a row come from one wave, in program order, so the sum has one fixed order.
+// All adds to an LDS row come from one wave, in program order, and the LDS rows are added in a
+// fixed order, so the sum has one fixed order.
 // Two things keep dense clumps from serialising the walk:
 //  * the runs of heavy cells (more than HEAVY_CELL particles) are summed once, for all eight
 //    corners, by k_heavy_pieces (one wave per piece, fixed butterfly); the walk takes a piece's
 //    sums from pre[] at the piece's first particle and jumps over the rest of the piece;
-//  * rows still fed by more than HEAVY_ROW particles are left to k_deposit_heavy, where the
-//    waves of a block each walk a contiguous slice of the runs into their own LDS row and the
-//    slices are added in wave order.
-constexpr uint32_t HEAVY_ROW = 2048;
+//  * rows with a source run of more than HEAVY_RUN particles are left to k_deposit_heavy, where
+//    several waves walk contiguous slices of each run into their own LDS rows and the rows are
+//    added in wave order.
+constexpr uint32_t HEAVY_RUN = 1024;
 
-// One wave per listed piece.  The piece is the part of the run of its first particle's cell that
-// lies before the next multiple of HEAVY_PIECE.  Its eight corner sums (mass * wx * wy * wz, left
+// One wave per listed piece: the part of the run of its first particle's cell up to the next
+// piece start.  Its eight corner sums (mass * wx * wy * wz, left
 // to right, functions.py:61-68; q = di + 2*dj + 4*dk) go to pre[q*cap + first]; skip[] gets, for
 // every particle of the piece, the index one past the piece (the first one also SKIP_HEAD).
 template <typename TP>
 __global__ void __launch_bounds__(BLOCK)
 k_heavy_pieces(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ piece_list,
-               const uint32_t *__restrict__ piece_count, double *__restrict__ pre, uint32_t *__restrict__ skip,
-               int64_t n, int64_t cap, pm_geom g)
+               const uint32_t *__restrict__ piece_count, uint32_t shard_cap, double *__restrict__ pre,
+               uint32_t *__restrict__ skip, int64_t n, int64_t cap, pm_geom g)
 {
-    const uint32_t cnt = *piece_count;
-    const uint32_t waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t e = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); e < cnt; e += waves) {
+    // blocks s, s + PIECE_SHARDS, ... serve shard s
+    const uint32_t shard = blockIdx.x % PIECE_SHARDS;
+    const uint32_t cnt = piece_count[shard * COUNTER_STRIDE];
+    const uint32_t waves = (gridDim.x / PIECE_SHARDS) * (BLOCK / 64);
+    piece_list += (size_t)shard * shard_cap;
+    for (uint32_t e = (blockIdx.x / PIECE_SHARDS) * (BLOCK / 64) + (threadIdx.x >> 6); e < cnt; e += waves) {
         const uint32_t first = piece_list[e];
         const uint32_t k0 = key[first];
-        int64_t bound = ((int64_t)(first / HEAVY_PIECE) + 1) * HEAVY_PIECE;
-        if (bound > n) bound = n;
+        // the piece ends where the run ends or at the next cut that starts a piece
+        int64_t bound = n;
+        for (int64_t c = ((int64_t)(first / HEAVY_PIECE) + 1) * HEAVY_PIECE; c < n; c += HEAVY_PIECE)
+            if (key[c] != k0 || piece_cut(key, c, k0, n)) { bound = c; break; }
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         uint32_t mine = 0;
         for (int64_t r = (int64_t)first + lane_id(); r < bound; r += 64) {
@@ -286,17 +292,32 @@ __device__ __forceinline__ void lds_add(double *p, double v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// What one lane holds of a 64-particle pass over a run.
+template <typename TP> struct pass_t { uint32_t sk; pm_prec<TP> p; };
+
+template <typename TP>
+__device__ __forceinline__ pass_t<TP> load_pass(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ skip,
+                                               uint32_t base, uint32_t end)
+{
+    pass_t<TP> t{};
+    const uint32_t r = base + lane_id();
+    if (r < end) { t.sk = skip[r]; t.p = P[r]; }
+    return t;
+}
+
 // One run of a source row into the LDS row `acc`, 64 particles per pass.  The particles are in
 // cell order, so the lanes of a pass hold non-decreasing k and the lanes that share a cell are
 // neighbours.  Where many lanes share cells their masses are first summed by a segmented scan
 // over the wave (fixed tree order) and only the last lane of every cell adds to LDS; otherwise
 // every lane adds its own.  A piece of a heavy cell is represented by its first particle alone,
 // which adds the sums k_heavy_pieces left in pre[]; when a pass ends inside a piece the walk
-// continues after it.
+// continues after it.  `cur` is the first pass, already loaded; the next pass is requested
+// before the current one is processed.
 template <typename TP>
 __device__ __forceinline__ void deposit_run(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key,
                                             const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
-                                            uint32_t beg, uint32_t end, int di, int dj, const pm_geom &g, double *acc)
+                                            uint32_t beg, uint32_t end, pass_t<TP> cur, int di, int dj, const pm_geom &g,
+                                            double *acc)
 {
     const int G = g.G;
     const int lane = lane_id();
@@ -305,9 +326,11 @@ __device__ __forceinline__ void deposit_run(const pm_prec<TP> *__restrict__ P, c
     while (base < end) {                                        // wave-uniform
         const uint32_t r = base + lane;
         const bool live = r < end;
-        uint32_t sk = 0u;
-        pm_prec<TP> p{};
-        if (live) { sk = skip[r]; p = P[r]; }                   // both loads in flight together
+        const uint32_t sk = cur.sk;
+        const pm_prec<TP> p = cur.p;
+        const uint32_t sk_last = __shfl(sk, 63) & ~SKIP_HEAD;   // 0 unless the pass ends inside a piece
+        const uint32_t next = (sk_last != 0u) ? sk_last : base + 64;
+        if (next < end) cur = load_pass(P, skip, next, end);    // in flight while this pass is summed
         int k = 0x7fffffff - lane;                              // idle lanes: distinct, never equal to a cell
         double lo = 0.0, hi = 0.0;
         bool add = false;
@@ -337,12 +360,11 @@ __device__ __forceinline__ void deposit_run(const pm_prec<TP> *__restrict__ P, c
             lds_add(&acc[k], lo);
             lds_add(&acc[(k + 1 == G) ? 0 : k + 1], hi);
         }
-        const uint32_t sk_last = __shfl(sk, 63) & ~SKIP_HEAD;   // 0 unless the pass ended inside a piece
-        base = (sk_last != 0u) ? sk_last : base + 64;
+        base = next;
     }
 }
 
-struct row_runs { uint32_t beg[4], end[4], total; };
+struct row_runs { uint32_t beg[4], end[4], longest; };
 
 // The four source rows of density row `row`, in the order (di,dj) = (0,0) (1,0) (0,1) (1,1).
 __device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uint32_t row, int G)
@@ -351,15 +373,18 @@ __device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uin
     int im = (i == 0) ? G - 1 : i - 1, jm = (j == 0) ? G - 1 : j - 1;
     uint32_t src[4] = {(uint32_t)(i * G + j), (uint32_t)(im * G + j), (uint32_t)(i * G + jm), (uint32_t)(im * G + jm)};
     row_runs t;
-    t.total = 0;
+    t.longest = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         t.beg[q] = rs[src[q]]; t.end[q] = rs[src[q] + 1];
-        t.total += t.end[q] - t.beg[q];
+        uint32_t len = t.end[q] - t.beg[q];
+        t.longest = len > t.longest ? len : t.longest;
     }
     return t;
 }
 
+// One wave per density row: the first pass of each of the four runs is requested before any is
+// processed, then the runs are walked in the order q = 0..3.
 template <typename TP>
 __global__ void __launch_bounds__(BLOCK)
 k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
@@ -374,22 +399,28 @@ k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ k
     double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
     float *out = density + (size_t)row * G;
     row_runs t = runs_of(rs, row, G);
-    if (t.total > HEAVY_ROW) {
-        if (lane_id() == 0) heavy_rows[atomicAdd(heavy_count, 1u)] = row;
+    if (t.longest > HEAVY_RUN) {
+        if (lane_id() == 0) {
+            const uint32_t shard = row % ROW_SHARDS;        // holds at most R / ROW_SHARDS + 1 rows
+            heavy_rows[(size_t)shard * (R / ROW_SHARDS + 1) + atomicAdd(heavy_count + shard * COUNTER_STRIDE, 1u)] = row;
+        }
         return;
     }
-    if (t.total == 0) {
+    if (t.longest == 0) {
         for (int c = lane_id(); c < G; c += 64) out[c] = 0.0f;
         return;
     }
+    pass_t<TP> first[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) first[q] = load_pass(P, skip, t.beg[q], t.end[q]);
     for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
-    deposit_run(P, key, skip, pre, cap, t.beg[0], t.end[0], 0, 0, g, acc);
-    deposit_run(P, key, skip, pre, cap, t.beg[1], t.end[1], 1, 0, g, acc);
-    deposit_run(P, key, skip, pre, cap, t.beg[2], t.end[2], 0, 1, g, acc);
-    deposit_run(P, key, skip, pre, cap, t.beg[3], t.end[3], 1, 1, g, acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) deposit_run(P, key, skip, pre, cap, t.beg[q], t.end[q], first[q], q & 1, q >> 1, g, acc);
     for (int c = lane_id(); c < G; c += 64) out[c] = (float)acc[c];
 }
 
+// Rows with a long run: a block of 4*S waves; wave w walks slice w/4 of run w%4 into its own LDS
+// row, and the rows are added in wave order.
 template <typename TP>
 __global__ void __launch_bounds__(1024)
 k_deposit_heavy(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
@@ -399,22 +430,23 @@ k_deposit_heavy(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ 
     extern __shared__ double lds_rows[];
     const int G = g.G;
     const int nw = blockDim.x >> 6, w = threadIdx.x >> 6;
+    const int q = w & 3, slice = w >> 2, slices = nw >> 2;
     double *acc = lds_rows + (size_t)w * G;
-    const uint32_t cnt = *heavy_count;
-    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {
+    // blocks s, s + ROW_SHARDS, ... serve shard s
+    const uint32_t shard = blockIdx.x % ROW_SHARDS;
+    const uint32_t cnt = heavy_count[shard * COUNTER_STRIDE];
+    heavy_rows += (size_t)shard * ((uint32_t)G * (uint32_t)G / ROW_SHARDS + 1);
+    for (uint32_t e = blockIdx.x / ROW_SHARDS; e < cnt; e += gridDim.x / ROW_SHARDS) {
         const uint32_t row = heavy_rows[e];
         row_runs t = runs_of(rs, row, G);
         for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // wave w takes the w-th slice of the run; slices are whole multiples of 64 particles
-            uint32_t len = t.end[q] - t.beg[q];
-            uint32_t sl = ((len + nw - 1) / nw + 63u) & ~63u;
-            uint32_t b = t.beg[q] + (uint32_t)w * sl, e2 = b + sl;
-            if (b > t.end[q]) b = t.end[q];
-            if (e2 > t.end[q]) e2 = t.end[q];
-            deposit_run(P, key, skip, pre, cap, b, e2, q & 1, q >> 1, g, acc);
-        }
+        // slices are whole multiples of 64 particles
+        uint32_t len = t.end[q] - t.beg[q];
+        uint32_t sl = ((len + slices - 1) / slices + 63u) & ~63u;
+        uint32_t b = t.beg[q] + (uint32_t)slice * sl, e2 = b + sl;
+        if (b > t.end[q]) b = t.end[q];
+        if (e2 > t.end[q]) e2 = t.end[q];
+        deposit_run(P, key, skip, pre, cap, b, e2, load_pass(P, skip, b, e2), q & 1, q >> 1, g, acc);
         __syncthreads();
         float *out = density + (size_t)row * G;
         for (int c = threadIdx.x; c < G; c += blockDim.x) {
@@ -448,7 +480,8 @@ template <typename TP, typename TV, bool FUSED>
 __global__ void __launch_bounds__(BLOCK)
 k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, pm_vrec<TV> *__restrict__ V,
          const float *__restrict__ gx, const float *__restrict__ gy, const float *__restrict__ gz,
-         const float *__restrict__ phi, float *__restrict__ forces, int64_t n, pm_geom g, double dt, bool integrate)
+         const float *__restrict__ phi, float *__restrict__ forces, uint32_t *__restrict__ key_next, int64_t n, pm_geom g,
+         double dt, bool integrate)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
@@ -548,6 +581,9 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
         o.z = wrap_f32((float)((double)p.z + mz), g.Lf);
     }
     Pout[r] = o;
+    // cell key of the new position, for the next step's binning
+    const cell_t cn = locate(o, g);
+    key_next[r] = (uint32_t)(((int64_t)cn.i * G + cn.j) * G + cn.k);
 }
 
 }  // namespace
@@ -582,14 +618,16 @@ hipError_t pm_launch_cell_keys(pm_ctx *c)
 hipError_t pm_launch_reorder(pm_ctx *c)
 {
     int64_t n = c->n;
+    hipError_t e = hipMemsetAsync(c->counters, 0, PM_NUM_COUNTERS * sizeof(uint32_t), c->stream);     // heavy rows, heavy-cell pieces
+    if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     int u = c->cur, w = 1 - u;
     if (c->pos_f64) {
-        if (c->vel_f64) k_reorder<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vd[u], c->vd[w], c->src, n);
-        else k_reorder<double, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vf[u], c->vf[w], c->src, n);
+        if (c->vel_f64) k_reorder<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vd[u], c->vd[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
+        else k_reorder<double, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vf[u], c->vf[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
     } else {
-        if (c->vel_f64) k_reorder<float, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vd[u], c->vd[w], c->src, n);
-        else k_reorder<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vf[u], c->vf[w], c->src, n);
+        if (c->vel_f64) k_reorder<float, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vd[u], c->vd[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
+        else k_reorder<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vf[u], c->vf[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
     }
     c->cur = w;
     return hipGetLastError();
@@ -598,16 +636,23 @@ hipError_t pm_launch_reorder(pm_ctx *c)
 hipError_t pm_launch_row_start(pm_ctx *c)
 {
     const uint32_t G = (uint32_t)c->g.G;
-    hipError_t e = hipMemsetAsync(c->counters, 0, 2 * sizeof(uint32_t), c->stream);
-    if (e != hipSuccess) return e;
-    k_row_start<<<grid_for(c->n + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, G, G * G, c->row_start, c->skip, c->piece_list, c->counters + 1);
+    k_row_start<<<grid_for((int64_t)G * G + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, G, G * G, c->row_start);
     return hipGetLastError();
 }
 
+uint32_t pm_piece_shard_cap(int64_t cap)
+{
+    uint32_t blocks = (uint32_t)((cap + BLOCK - 1) / BLOCK);
+    return ((blocks + PIECE_SHARDS - 1) / PIECE_SHARDS) * PIECES_PER_BLOCK;
+}
+
+size_t pm_piece_list_entries(int64_t cap) { return (size_t)pm_piece_shard_cap(cap) * PIECE_SHARDS; }
+size_t pm_heavy_row_entries(int G) { return ((size_t)G * G / ROW_SHARDS + 1) * ROW_SHARDS; }
+
 static int heavy_waves(int G)
 {
-    int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double)));
-    return nw > 16 ? 16 : (nw < 1 ? 1 : nw);
+    int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double))) & ~3;     // a multiple of 4: waves per run
+    return nw > 16 ? 16 : (nw < 4 ? 4 : nw);
 }
 
 template <typename TP>
@@ -615,9 +660,10 @@ static hipError_t deposit_dispatch(pm_ctx *c, const pm_prec<TP> *P)
 {
     const int G = c->g.G;
     const uint32_t R = (uint32_t)G * (uint32_t)G;
-    hipError_t e = hipMemsetAsync(c->counters, 0, sizeof(uint32_t), c->stream);     // heavy rows; the piece count stays
+    hipError_t e = hipMemsetAsync(c->counters, 0, PM_PIECE_COUNTERS * sizeof(uint32_t), c->stream);     // heavy rows; the piece counts stay
     if (e != hipSuccess) return e;
-    k_heavy_pieces<TP><<<1024, BLOCK, 0, c->stream>>>(P, c->key_out, c->piece_list, c->counters + 1, c->pre, c->skip, c->n, c->cap, c->g);
+    k_heavy_pieces<TP><<<PIECE_SHARDS * 32, BLOCK, 0, c->stream>>>(P, c->key_out, c->piece_list, c->counters + PM_PIECE_COUNTERS,
+                                                                 pm_piece_shard_cap(c->cap), c->pre, c->skip, c->n, c->cap, c->g);
     const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double);
     k_deposit_rows<TP><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
         P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->heavy_rows, c->counters, c->g);
@@ -647,9 +693,9 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *V, dou
     int64_t n = c->n;
     pm_prec<float> *out = c->pf[c->cur];
     if (fused)
-        k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, nullptr, nullptr, nullptr, c->potential, forces, n, c->g, dt, integrate);
+        k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate);
     else
-        k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, n, c->g, dt, integrate);
+        k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate);
 }
 
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient)
