@@ -162,22 +162,8 @@ static int create_impl(pm_ctx *c)
 
     std::call_once(g_fft_once, [] { rocfft_setup(); });
     if (c->fft_custom) {
-        // z axis: batched 1-D real transforms, one per mesh row, into / out of rows of pitch Ghp
         HIP_TRY(c, pm_fft_upload_twiddles(c));
-        const size_t len1[1] = {(size_t)G}, one[1] = {1};
-        rocfft_plan_description df = nullptr, di = nullptr;
-        FFT_TRY(c, rocfft_plan_description_create(&df));
-        FFT_TRY(c, rocfft_plan_description_set_data_layout(df, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved,
-                                                           nullptr, nullptr, 1, one, (size_t)G, 1, one, (size_t)c->g.Ghp));
-        FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                      rocfft_precision_single, 1, len1, (size_t)G * G, df));
-        FFT_TRY(c, rocfft_plan_description_create(&di));
-        FFT_TRY(c, rocfft_plan_description_set_data_layout(di, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real,
-                                                           nullptr, nullptr, 1, one, (size_t)c->g.Ghp, 1, one, (size_t)G));
-        FFT_TRY(c, rocfft_plan_create(&c->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                      rocfft_precision_single, 1, len1, (size_t)G * G, di));
-        rocfft_plan_description_destroy(df);
-        rocfft_plan_description_destroy(di);
+        return PM_OK;
     } else {
         const size_t lengths[3] = {(size_t)G, (size_t)G, (size_t)G};
         FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
@@ -276,9 +262,13 @@ int pm_potential(pm_ctx *c)
     HIP_TRY(c, hipSetDevice(c->device));
     {
         stage_timer t(c, PM_STAGE_FFT_FWD);
-        void *in[1] = {c->density}, *out[1] = {c->spectrum};
-        FFT_TRY(c, rocfft_execute(c->fwd, in, out, c->info));
-        if (c->fft_custom) HIP_TRY(c, pm_launch_col_fft(c, -1));
+        if (c->fft_custom) {
+            HIP_TRY(c, pm_launch_row_fft(c, true));
+            HIP_TRY(c, pm_launch_col_fft(c, -1));
+        } else {
+            void *in[1] = {c->density}, *out[1] = {c->spectrum};
+            FFT_TRY(c, rocfft_execute(c->fwd, in, out, c->info));
+        }
     }
     {
         stage_timer t(c, PM_STAGE_GREEN);
@@ -287,9 +277,13 @@ int pm_potential(pm_ctx *c)
     }
     {
         stage_timer t(c, PM_STAGE_FFT_INV);
-        if (c->fft_custom) HIP_TRY(c, pm_launch_col_fft(c, 1));
-        void *in[1] = {c->spectrum}, *out[1] = {c->potential};
-        FFT_TRY(c, rocfft_execute(c->inv, in, out, c->info));
+        if (c->fft_custom) {
+            HIP_TRY(c, pm_launch_col_fft(c, 1));
+            HIP_TRY(c, pm_launch_row_fft(c, false));
+        } else {
+            void *in[1] = {c->spectrum}, *out[1] = {c->potential};
+            FFT_TRY(c, rocfft_execute(c->inv, in, out, c->info));
+        }
     }
     return PM_OK;
 }

@@ -183,6 +183,125 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
     }
 }
 
+// ---- z axis: real <-> half-complex transforms of contiguous rows ----------------------------------
+//
+// One wave per mesh row.  A row of N = 512 reals is read as 256 complex numbers z[n] = x[2n] + i x[2n+1],
+// transformed by a 256-point radix-4 Stockham FFT (one butterfly per lane per stage, lane j always
+// reading elements j + 64 r), and split into the 257 values of the half spectrum:
+//   X[k] = (Z[k] + conj Z[256-k])/2 - (i/2) w^k (Z[k] - conj Z[256-k]),   w = exp(-2 pi i / 512).
+// The inverse runs the same steps backwards:
+//   Z[k] = (X[k] + conj X[256-k]) + i w^-k (X[k] - conj X[256-k]),  z = unnormalised inverse FFT of Z.
+// Every global access of a wave is a contiguous 512-byte run.
+
+template <int DIR> __device__ __forceinline__ void fft4(float2 *v)
+{
+    float2 a0 = cadd(v[0], v[2]), a2 = csub(v[0], v[2]);
+    float2 a1 = cadd(v[1], v[3]), a3 = rot90<DIR>(csub(v[1], v[3]));
+    v[0] = cadd(a0, a1); v[2] = csub(a0, a1); v[1] = cadd(a2, a3); v[3] = csub(a2, a3);
+}
+
+// 256-point FFT of the values a wave holds as v[r] = element (lane + 64 r); result in the same form.
+// `buf` is the wave's 256-element LDS exchange buffer, `tw` the 512-entry twiddle table in LDS.
+template <int DIR>
+__device__ __forceinline__ void wave_fft256(float2 *v, float2 *buf, const float2 *tw, int j)
+{
+    fft4<DIR>(v);                                       // stage 1, Ns = 1: no twiddles
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[4 * j + r] = v[r];
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {                       // Ns = 4, 16, 64
+        const int Ns = 1 << (2 * s), k = j & (Ns - 1), step = 128 >> (2 * s);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = buf[j + 64 * r];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], twid<DIR>(tw[r * k * step]));
+        fft4<DIR>(v);
+        if (s < 3) {
+            __syncthreads();
+            const int j0 = ((j >> (2 * s)) << (2 * s + 2)) + k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[j0 + r * Ns] = v[r];
+        }
+    }
+}
+
+constexpr int ROWS_PER_WAVE = 4;
+
+__global__ void __launch_bounds__(FFT_BLOCK)
+k_row_r2c512(const float *__restrict__ in, float2 *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
+{
+    __shared__ float2 tw[512];
+    __shared__ float2 bufs[FFT_BLOCK / 64][256];
+    const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float2 *buf = bufs[w];
+    for (int q = threadIdx.x; q < 512; q += FFT_BLOCK) tw[q] = twiddle[q];
+    const int64_t row0 = ((int64_t)blockIdx.x * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+        const float2 *src = (const float2 *)(in + (row0 + rr) * 512);
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = src[j + 64 * r];
+        __syncthreads();                                // twiddles in place / previous row's buffer reads done
+        wave_fft256<-1>(v, buf, tw, j);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[j + 64 * r] = v[r];
+        __syncthreads();
+        float2 *dst = out + (row0 + rr) * pitch;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = j + 64 * r;
+            const float2 zk = v[r], zp = buf[(256 - k) & 255];
+            const float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));      // (Z[k] + conj Z[256-k]) / 2
+            const float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));      // (Z[k] - conj Z[256-k]) / 2
+            const float2 t = cmul(tw[k], d);                                               // w^k d
+            dst[k] = make_float2(e.x + t.y, e.y - t.x);                                    // e - i t
+            if (k == 0) dst[256] = make_float2(zk.x - zk.y, 0.0f);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FFT_BLOCK)
+k_row_c2r512(const float2 *__restrict__ in, float *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
+{
+    __shared__ float2 tw[512];
+    __shared__ float2 bufs[FFT_BLOCK / 64][260];
+    const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float2 *buf = bufs[w];
+    for (int q = threadIdx.x; q < 512; q += FFT_BLOCK) tw[q] = twiddle[q];
+    const int64_t row0 = ((int64_t)blockIdx.x * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+        const float2 *src = in + (row0 + rr) * pitch;
+        float2 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = src[j + 64 * r];
+        float2 xn = (j == 0) ? src[256] : make_float2(0.0f, 0.0f);
+        __syncthreads();                                // twiddles in place / previous row's buffer reads done
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[j + 64 * r] = x[r];
+        if (j == 0) buf[256] = xn;
+        __syncthreads();
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = j + 64 * r;
+            float2 xk = x[r], xp = buf[256 - k];
+            if (k == 0) { xk.y = 0.0f; xp.y = 0.0f; }                      // X[0] and X[256] of a real row are real
+            const float2 e = make_float2(xk.x + xp.x, xk.y - xp.y);        // X[k] + conj X[256-k]
+            const float2 d = make_float2(xk.x - xp.x, xk.y + xp.y);        // X[k] - conj X[256-k]
+            const float2 wk = tw[k];
+            const float2 t = cmul(make_float2(wk.x, -wk.y), d);            // w^-k d
+            v[r] = make_float2(e.x - t.y, e.y + t.x);                      // e + i t
+        }
+        __syncthreads();
+        wave_fft256<1>(v, buf, tw, j);
+        float2 *dst = (float2 *)(out + (row0 + rr) * 512);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[j + 64 * r] = v[r];
+    }
+}
+
 constexpr size_t LDS_BYTES_512 = (512 * COLS + 512) * sizeof(float2);
 
 template <int DIR, bool GREEN>
@@ -220,6 +339,16 @@ hipError_t pm_fft_upload_twiddles(pm_ctx *c)
     hipError_t e = hipMalloc((void **)&c->twiddle, G * sizeof(float2));
     if (e != hipSuccess) return e;
     return hipMemcpy(c->twiddle, w.data(), G * sizeof(float2), hipMemcpyHostToDevice);
+}
+
+// z axis: density (G,G,G) -> half spectrum (forward), half spectrum -> potential (inverse)
+hipError_t pm_launch_row_fft(pm_ctx *c, bool forward)
+{
+    const int G = c->g.G;
+    const int blocks = (int)((int64_t)G * G / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
+    if (forward) k_row_r2c512<<<blocks, FFT_BLOCK, 0, c->stream>>>(c->density, c->spectrum, c->g.Ghp, c->twiddle);
+    else k_row_c2r512<<<blocks, FFT_BLOCK, 0, c->stream>>>(c->spectrum, c->potential, c->g.Ghp, c->twiddle);
+    return hipGetLastError();
 }
 
 // dir < 0: forward along j.  dir > 0: inverse along j.  dir == 0: forward along i, Green multiply, inverse along i.

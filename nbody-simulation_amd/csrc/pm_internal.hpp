@@ -70,7 +70,7 @@ struct pm_ctx {
     float *density = nullptr, *potential = nullptr, *grad[3] = {};
     float2 *spectrum = nullptr;         // (G, G, Ghp) complex64
     float2 *twiddle = nullptr;          // exp(-2 pi i q / G), q < G (column FFT kernels)
-    bool fft_custom = false;            // z axis by rocFFT (batched 1-D), y and x axes by the column kernels
+    bool fft_custom = false;            // all three axes by the hand-written kernels (no rocFFT plan)
     rocfft_plan fwd = nullptr, inv = nullptr;
     rocfft_execution_info info = nullptr;
     void *fft_work = nullptr;
@@ -107,6 +107,7 @@ bool pm_fft_custom_supported(int G);
 int pm_fft_pitch(int G);
 hipError_t pm_fft_upload_twiddles(pm_ctx *c);
 hipError_t pm_launch_col_fft(pm_ctx *c, int dir);
+hipError_t pm_launch_row_fft(pm_ctx *c, bool forward);
 hipError_t pm_launch_gradient(pm_ctx *c);
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);
 hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos);
