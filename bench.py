@@ -95,11 +95,14 @@ def cpu_baseline(pos, vel, mass, G, L, dt):
     from oracle import pm_oracle as O
     O.build()
     O.cell_keys(pos[:1000], G, L)                 # load the library outside the timed region
+    steps = 3
     t0 = time.perf_counter()
-    O.pm_step(pos, vel, mass, G, L, dt)
+    x, v = pos, vel
+    for _ in range(steps):
+        x, v = O.pm_step(x, v, mass, G, L, dt)
     dt_s = time.perf_counter() - t0
-    return {"value": len(pos) / dt_s, "unit": "particle-updates/s", "cores": 1, "kind": "port",
-            "sample": f"1 full PM step of the same workload (N={len(pos)}, G={G}) in {dt_s:.1f} s: C loops for "
+    return {"value": steps * len(pos) / dt_s, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} full PM steps of the same workload (N={len(pos)}, G={G}) in {dt_s:.1f} s: C loops for "
                       "deposit/gather, numpy/scipy.fft (1 worker) for Poisson/gradient/integrator",
             "host_cpus": os.cpu_count()}
 
