@@ -88,6 +88,7 @@ int ensure_binned(pm_ctx *c)
 {
     if (c->binned) return PM_OK;
     stage_timer t(c, PM_STAGE_BIN);
+    HIP_TRY(c, pm_settle_velocities(c));        // src is about to be overwritten
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
     c->keys_fresh = false;      // the sort consumes key_in
     HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
@@ -229,7 +230,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     c->pos_in_f64 = c->pos_f64 = (pos_dtype == PM_F64);
     c->vel_f64 = (vel_dtype == PM_F64);
     TRY(alloc_particles(c));
-    c->n = n; c->cur = 0; c->binned = false; c->have_forces = false; c->keys_fresh = false;
+    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->keys_fresh = false;
     size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
     if (n > 0) {
         // staging: positions (n,3), then the masses behind them

@@ -44,6 +44,8 @@ struct pm_ctx {
     // reorder.  Positions are float32 except between pm_set_particles(PM_F64) and the first
     // drift, when pd[] holds them.
     int cur = 0;
+    int vcur = 0;               // live velocity buffer
+    bool v_stale = false;       // velocity slot r still sits at slot src[r] of vf/vd[vcur] (one reorder behind)
     pm_prec<float> *pf[2] = {};
     pm_prec<double> *pd[2] = {};
     pm_vrec<float> *vf[2] = {};
@@ -100,6 +102,7 @@ hipError_t pm_launch_cell_keys(pm_ctx *c);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);
 size_t pm_sort_tmp_bytes(int64_t cap);
 hipError_t pm_launch_reorder(pm_ctx *c);
+hipError_t pm_settle_velocities(pm_ctx *c);     // must run before src is overwritten by a new sort
 hipError_t pm_launch_row_start(pm_ctx *c);
 hipError_t pm_launch_deposit(pm_ctx *c);
 hipError_t pm_launch_green(pm_ctx *c);

@@ -93,18 +93,20 @@ __global__ void k_pack_vel(const TV *__restrict__ aos, pm_vrec<TV> *__restrict__
 }
 
 template <typename TP, typename TV>
-__global__ void k_export_pos(const pm_prec<TP> *__restrict__ P, const pm_vrec<TV> *__restrict__ V, TP *__restrict__ aos, int64_t n)
+__global__ void k_export_pos(const pm_prec<TP> *__restrict__ P, const pm_vrec<TV> *__restrict__ V, const uint32_t *__restrict__ vmap,
+                             TP *__restrict__ aos, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
     pm_prec<TP> rec = P[r];
-    int64_t o = 3 * (int64_t)V[r].id;
+    int64_t o = 3 * (int64_t)V[vmap ? vmap[r] : r].id;
     aos[o] = rec.x; aos[o + 1] = rec.y; aos[o + 2] = rec.z;
 }
 
 template <typename TV>
 __global__ void k_export_vel(const pm_vrec<TV> *__restrict__ V, TV *__restrict__ aos, int64_t n)
 {
+    // velocity records carry their own particle index, so their storage order does not matter here
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
     pm_vrec<TV> rec = V[r];
@@ -113,22 +115,23 @@ __global__ void k_export_vel(const pm_vrec<TV> *__restrict__ V, TV *__restrict__
 }
 
 template <typename TV>
-__global__ void k_export_forces(const float *__restrict__ in, const pm_vrec<TV> *__restrict__ V, float *__restrict__ out, int64_t n)
+__global__ void k_export_forces(const float *__restrict__ in, const pm_vrec<TV> *__restrict__ V, const uint32_t *__restrict__ vmap,
+                                float *__restrict__ out, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
-    int64_t o = 3 * (int64_t)V[r].id;
+    int64_t o = 3 * (int64_t)V[vmap ? vmap[r] : r].id;
     out[o] = in[3 * r]; out[o + 1] = in[3 * r + 1]; out[o + 2] = in[3 * r + 2];
 }
 
 template <typename TV>
-__global__ void k_export_keys(const uint32_t *__restrict__ key, const pm_vrec<TV> *__restrict__ V,
+__global__ void k_export_keys(const uint32_t *__restrict__ key, const pm_vrec<TV> *__restrict__ V, const uint32_t *__restrict__ vmap,
                               int64_t *__restrict__ keys, int64_t *__restrict__ perm, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
     keys[r] = (int64_t)key[r];
-    perm[r] = (int64_t)V[r].id;
+    perm[r] = (int64_t)V[vmap ? vmap[r] : r].id;
 }
 
 // ---- binning -------------------------------------------------------------------------------
@@ -142,7 +145,9 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
     key[p] = (uint32_t)(((int64_t)c.i * g.G + c.j) * g.G + c.k);
 }
 
-// Cell order -> storage order.  Slot r of the new storage takes the records of old slot src[r].
+// Cell order -> storage order.  Slot r of the new storage takes the position record of old slot
+// src[r].  The velocity records are not moved here: the gather, which reads and writes every one of
+// them anyway, reads record src[r] and writes it to slot r (k_move_v does it when no gather follows).
 //
 // The same pass prepares the deposit's handling of "heavy" cells (more than HEAVY_CELL
 // particles): it clears skip[] and cuts the runs of heavy cells into pieces for k_heavy_pieces.
@@ -163,9 +168,15 @@ __device__ __forceinline__ bool piece_cut(const uint32_t *__restrict__ key, int6
     return c >= HEAVY_CELL && c + HEAVY_CELL - 1 < n && key[c - HEAVY_CELL] == k && key[c + HEAVY_CELL - 1] == k;
 }
 
-template <typename TP, typename TV>
+template <typename TV>
+__global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__restrict__ Vout, const uint32_t *__restrict__ src, int64_t n)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r < n) Vout[r] = Vin[src[r]];
+}
+
+template <typename TP>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
-                          const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__restrict__ Vout,
                           const uint32_t *__restrict__ src, const uint32_t *__restrict__ key, uint32_t *__restrict__ skip,
                           uint32_t *__restrict__ piece_list, uint32_t *__restrict__ piece_count, uint32_t shard_cap, int64_t n)
 {
@@ -174,7 +185,6 @@ __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__re
     if (r < n) {
         int64_t s = src[r];
         Pout[r] = Pin[s];
-        Vout[r] = Vin[s];
         skip[r] = 0u;
         uint32_t kcur = key[r];
         bool head = (r == 0) || key[r - 1] != kcur;
@@ -478,7 +488,8 @@ __device__ constexpr int DI[8] = {0, 1, 0, 0, 1, 1, 0, 1}, DJ[8] = {0, 0, 1, 0, 
 
 template <typename TP, typename TV, bool FUSED>
 __global__ void __launch_bounds__(BLOCK)
-k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, pm_vrec<TV> *__restrict__ V,
+k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, const pm_vrec<TV> *__restrict__ Vin,
+         pm_vrec<TV> *__restrict__ Vout, const uint32_t *__restrict__ vmap,
          const float *__restrict__ gx, const float *__restrict__ gy, const float *__restrict__ gz,
          const float *__restrict__ phi, float *__restrict__ forces, uint32_t *__restrict__ key_next, int64_t n, pm_geom g,
          double dt, bool integrate)
@@ -559,11 +570,11 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     // main.py:58-60
     const float dtf = (float)dt;
     float dvx = fx * dtf, dvy = fy * dtf, dvz = fz * dtf;      // float32 product (weak Python float)
-    pm_vrec<TV> v = V[r];
+    pm_vrec<TV> v = Vin[vmap ? vmap[r] : r];
     // velocities += forces*dt : the add runs in the velocities' dtype
     if constexpr (sizeof(TV) == 4) { v.x = v.x + dvx; v.y = v.y + dvy; v.z = v.z + dvz; }
     else { v.x = v.x + (double)dvx; v.y = v.y + (double)dvy; v.z = v.z + (double)dvz; }
-    V[r] = v;
+    Vout[r] = v;
     // positions += velocities*dt : float32 product for float32 velocities, the add in the wider
     // of the two dtypes, the result cast to float32 (on store, or by .astype at main.py:60)
     pm_prec<float> o;
@@ -599,8 +610,8 @@ hipError_t pm_launch_pack(pm_ctx *c, const void *pos_aos, const float *mass, con
         if (c->pos_f64) k_pack_pos<double><<<grid_for(n), BLOCK, 0, c->stream>>>((const double *)pos_aos, mass, c->pd[u], n);
         else k_pack_pos<float><<<grid_for(n), BLOCK, 0, c->stream>>>((const float *)pos_aos, mass, c->pf[u], n);
     } else {
-        if (c->vel_f64) k_pack_vel<double><<<grid_for(n), BLOCK, 0, c->stream>>>((const double *)vel_aos, c->vd[u], n);
-        else k_pack_vel<float><<<grid_for(n), BLOCK, 0, c->stream>>>((const float *)vel_aos, c->vf[u], n);
+        if (c->vel_f64) k_pack_vel<double><<<grid_for(n), BLOCK, 0, c->stream>>>((const double *)vel_aos, c->vd[c->vcur], n);
+        else k_pack_vel<float><<<grid_for(n), BLOCK, 0, c->stream>>>((const float *)vel_aos, c->vf[c->vcur], n);
     }
     return hipGetLastError();
 }
@@ -615,6 +626,17 @@ hipError_t pm_launch_cell_keys(pm_ctx *c)
     return hipGetLastError();
 }
 
+// Bring the velocity records into the current storage order (they lag one reorder behind).
+static hipError_t settle_velocities(pm_ctx *c)
+{
+    if (!c->v_stale || c->n == 0) { c->v_stale = false; return hipSuccess; }
+    int u = c->vcur, w = 1 - u;
+    if (c->vel_f64) k_move_v<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->vd[u], c->vd[w], c->src, c->n);
+    else k_move_v<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->vf[u], c->vf[w], c->src, c->n);
+    c->vcur = w; c->v_stale = false;
+    return hipGetLastError();
+}
+
 hipError_t pm_launch_reorder(pm_ctx *c)
 {
     int64_t n = c->n;
@@ -622,16 +644,15 @@ hipError_t pm_launch_reorder(pm_ctx *c)
     if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     int u = c->cur, w = 1 - u;
-    if (c->pos_f64) {
-        if (c->vel_f64) k_reorder<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vd[u], c->vd[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
-        else k_reorder<double, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->vf[u], c->vf[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
-    } else {
-        if (c->vel_f64) k_reorder<float, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vd[u], c->vd[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
-        else k_reorder<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->vf[u], c->vf[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, pm_piece_shard_cap(c->cap), n);
-    }
+    const uint32_t cap = pm_piece_shard_cap(c->cap);
+    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n);
+    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n);
     c->cur = w;
+    c->v_stale = true;
     return hipGetLastError();
 }
+
+hipError_t pm_settle_velocities(pm_ctx *c) { return settle_velocities(c); }
 
 hipError_t pm_launch_row_start(pm_ctx *c)
 {
@@ -688,14 +709,17 @@ hipError_t pm_launch_deposit(pm_ctx *c)
 }
 
 template <typename TP, typename TV>
-static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *V, double dt, bool integrate, float *forces, bool fused)
+static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const V[2], double dt, bool integrate, float *forces, bool fused)
 {
     int64_t n = c->n;
     pm_prec<float> *out = c->pf[c->cur];
+    const pm_vrec<TV> *vin = V[c->vcur];
+    pm_vrec<TV> *vout = c->v_stale ? V[1 - c->vcur] : V[c->vcur];
+    const uint32_t *vmap = c->v_stale ? c->src : nullptr;
     if (fused)
-        k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate);
+        k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate);
     else
-        k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, V, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate);
+        k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate);
 }
 
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient)
@@ -704,12 +728,13 @@ hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_for
     int u = c->cur;
     float *f = store_forces ? c->forces : nullptr;
     if (c->pos_f64) {
-        if (c->vel_f64) gather_dispatch<double, double>(c, c->pd[u], c->vd[u], dt, integrate, f, fused_gradient);
-        else gather_dispatch<double, float>(c, c->pd[u], c->vf[u], dt, integrate, f, fused_gradient);
+        if (c->vel_f64) gather_dispatch<double, double>(c, c->pd[u], c->vd, dt, integrate, f, fused_gradient);
+        else gather_dispatch<double, float>(c, c->pd[u], c->vf, dt, integrate, f, fused_gradient);
     } else {
-        if (c->vel_f64) gather_dispatch<float, double>(c, c->pf[u], c->vd[u], dt, integrate, f, fused_gradient);
-        else gather_dispatch<float, float>(c, c->pf[u], c->vf[u], dt, integrate, f, fused_gradient);
+        if (c->vel_f64) gather_dispatch<float, double>(c, c->pf[u], c->vd, dt, integrate, f, fused_gradient);
+        else gather_dispatch<float, float>(c, c->pf[u], c->vf, dt, integrate, f, fused_gradient);
     }
+    if (integrate && c->v_stale) { c->vcur = 1 - c->vcur; c->v_stale = false; }     // the gather moved the velocity records
     return hipGetLastError();
 }
 
@@ -717,19 +742,20 @@ hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos)
 {
     int64_t n = c->n;
     if (n == 0) return hipSuccess;
-    int u = c->cur;
+    int u = c->cur, v = c->vcur;
+    const uint32_t *vmap = c->v_stale ? c->src : nullptr;
     if (pos_aos) {
         if (c->pos_f64) {
-            if (c->vel_f64) k_export_pos<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->vd[u], (double *)pos_aos, n);
-            else k_export_pos<double, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->vf[u], (double *)pos_aos, n);
+            if (c->vel_f64) k_export_pos<double, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->vd[v], vmap, (double *)pos_aos, n);
+            else k_export_pos<double, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->vf[v], vmap, (double *)pos_aos, n);
         } else {
-            if (c->vel_f64) k_export_pos<float, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->vd[u], (float *)pos_aos, n);
-            else k_export_pos<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->vf[u], (float *)pos_aos, n);
+            if (c->vel_f64) k_export_pos<float, double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->vd[v], vmap, (float *)pos_aos, n);
+            else k_export_pos<float, float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->vf[v], vmap, (float *)pos_aos, n);
         }
     }
     if (vel_aos) {
-        if (c->vel_f64) k_export_vel<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vd[u], (double *)vel_aos, n);
-        else k_export_vel<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vf[u], (float *)vel_aos, n);
+        if (c->vel_f64) k_export_vel<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vd[v], (double *)vel_aos, n);
+        else k_export_vel<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->vf[v], (float *)vel_aos, n);
     }
     return hipGetLastError();
 }
@@ -737,15 +763,17 @@ hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos)
 hipError_t pm_launch_export_forces(pm_ctx *c, float *aos)
 {
     if (c->n == 0) return hipSuccess;
-    if (c->vel_f64) k_export_forces<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vd[c->cur], aos, c->n);
-    else k_export_forces<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vf[c->cur], aos, c->n);
+    const uint32_t *vmap = c->v_stale ? c->src : nullptr;
+    if (c->vel_f64) k_export_forces<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vd[c->vcur], vmap, aos, c->n);
+    else k_export_forces<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vf[c->vcur], vmap, aos, c->n);
     return hipGetLastError();
 }
 
 hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
 {
     if (c->n == 0) return hipSuccess;
-    if (c->vel_f64) k_export_keys<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vd[c->cur], keys, perm, c->n);
-    else k_export_keys<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vf[c->cur], keys, perm, c->n);
+    const uint32_t *vmap = c->v_stale ? c->src : nullptr;
+    if (c->vel_f64) k_export_keys<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vd[c->vcur], vmap, keys, perm, c->n);
+    else k_export_keys<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vf[c->vcur], vmap, keys, perm, c->n);
     return hipGetLastError();
 }
