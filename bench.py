@@ -85,7 +85,14 @@ def make_workload(name, n, L, seed):
     raise ValueError(name)
 
 
-def stage_bytes(n, m):
+def stage_bytes(n, m, fused=False):
+    """Algorithmic bytes of each timed stage; they add up to 64 N + 80 M.  Staged: deposit, three forward
+    axis passes, Green multiply (no traffic of its own), three inverse passes, gradient, gather.  Fused
+    (G = 512): the deposit kernel also does the forward z pass, the `green` kernel is the forward and
+    inverse x passes around the multiply, and the gather also differences the potential."""
+    if fused:
+        return {"bin": 0, "deposit": 16 * n + 4 * m + 8 * m, "fft_fwd": 8 * m, "green": 16 * m, "fft_inv": 16 * m,
+                "gradient": 0, "gather": 48 * n + 12 * m + 16 * m}
     return {"bin": 0, "deposit": 16 * n + 4 * m, "fft_fwd": 24 * m, "green": 0, "fft_inv": 24 * m,
             "gradient": 16 * m, "gather": 48 * n + 12 * m}
 
@@ -166,7 +173,7 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        b = stage_bytes(n, m)
+        b = stage_bytes(n, m, fused and G == 512)
         per = {s: (ms / c if c else 0.0) for s, (ms, c) in stages.items()}
         dom = max((s for s in per if b[s] > 0), key=lambda s: per[s])
         ach = b[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0

@@ -41,7 +41,9 @@ enum { PM_MESH_DENSITY = 0, PM_MESH_POTENTIAL = 1, PM_MESH_GX = 2, PM_MESH_GY = 
 /* pm_create flags */
 enum {
     PM_FLAG_TIMING = 1u,      /* record HIP events around every stage (pm_stage_times) */
-    PM_FLAG_FUSED_GRADIENT = 2u, /* pm_step differences the potential inside the gather instead of writing gx,gy,gz */
+    PM_FLAG_FUSED_GRADIENT = 2u, /* pm_step keeps intermediate meshes on chip where it can: the potential is differenced
+                                    inside the gather (no gx,gy,gz), and at grid_size 512 the deposit emits each density
+                                    row already transformed along z (no density mesh) */
     PM_FLAG_ROCFFT_ONLY = 4u  /* pm_create only: 3-D rocFFT plans for every grid size (no hand-written column FFT) */
 };
 

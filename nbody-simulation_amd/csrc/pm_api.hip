@@ -247,24 +247,27 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     return PM_OK;
 }
 
-int pm_deposit(pm_ctx *c)
+static int deposit_impl(pm_ctx *c, bool to_spectrum)
 {
     TRY(need_particles(c));
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(ensure_binned(c));
     stage_timer t(c, PM_STAGE_DEPOSIT);
-    HIP_TRY(c, pm_launch_deposit(c));
+    HIP_TRY(c, pm_launch_deposit(c, to_spectrum));
     return PM_OK;
 }
 
-int pm_potential(pm_ctx *c)
+int pm_deposit(pm_ctx *c) { return deposit_impl(c, false); }
+
+// have_z: the half spectrum already holds the z-transformed density rows (fused deposit)
+static int potential_impl(pm_ctx *c, bool have_z)
 {
     if (!c) return PM_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     {
         stage_timer t(c, PM_STAGE_FFT_FWD);
         if (c->fft_custom) {
-            HIP_TRY(c, pm_launch_row_fft(c, true));
+            if (!have_z) HIP_TRY(c, pm_launch_row_fft(c, true));
             HIP_TRY(c, pm_launch_col_fft(c, -1));
         } else {
             void *in[1] = {c->density}, *out[1] = {c->spectrum};
@@ -288,6 +291,8 @@ int pm_potential(pm_ctx *c)
     }
     return PM_OK;
 }
+
+int pm_potential(pm_ctx *c) { return potential_impl(c, false); }
 
 int pm_gradient(pm_ctx *c)
 {
@@ -332,8 +337,10 @@ int pm_step(pm_ctx *c, double dt, int nsteps)
     if (nsteps < 0) return fail(c, PM_EINVAL, "nsteps < 0");
     const bool fused = (c->flags & PM_FLAG_FUSED_GRADIENT) != 0;
     for (int s = 0; s < nsteps; ++s) {
-        TRY(pm_deposit(c));
-        TRY(pm_potential(c));
+        // fused mode on the hand-written FFT path: the deposit leaves z-transformed rows, no density mesh
+        const bool z_in_deposit = fused && c->fft_custom;
+        TRY(deposit_impl(c, z_in_deposit));
+        TRY(potential_impl(c, z_in_deposit));
         if (!fused) TRY(pm_gradient(c));
         TRY(gather_kick_drift(c, dt, fused));
     }

@@ -14,42 +14,17 @@
 // Stockham schedule ends the forward transform holding exactly the rows (n + 64 r) that the
 // first inverse stage starts from.
 #include "pm_internal.hpp"
+#include "pm_fft_dev.hpp"
 
 #include <cmath>
 #include <vector>
 
 namespace {
 
+using namespace pmfft;
+
 constexpr int COLS = 16;
 constexpr int FFT_BLOCK = 256;
-
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-// multiply by -i (forward) or +i (inverse)
-template <int DIR> __device__ __forceinline__ float2 rot90(float2 a)
-{
-    return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
-}
-template <int DIR> __device__ __forceinline__ float2 twid(float2 w) { return DIR < 0 ? w : make_float2(w.x, -w.y); }
-
-// 8-point DFT, in place, natural order in and out.  DIR = -1 forward (exp(-2 pi i nk/8)), +1 inverse.
-template <int DIR> __device__ __forceinline__ void fft8(float2 *v)
-{
-    const float h = 0.70710678118654752440f;
-    float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-    float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-    float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
-    float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
-    // a5 *= w8, a6 *= w8^2, a7 *= w8^3 with w8 = exp(DIR * i pi/4)
-    a5 = DIR < 0 ? make_float2(h * (a5.x + a5.y), h * (a5.y - a5.x)) : make_float2(h * (a5.x - a5.y), h * (a5.y + a5.x));
-    a6 = rot90<DIR>(a6);
-    a7 = DIR < 0 ? make_float2(h * (a7.y - a7.x), -h * (a7.x + a7.y)) : make_float2(-h * (a7.x + a7.y), h * (a7.x - a7.y));
-    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = rot90<DIR>(csub(a1, a3));
-    float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, a7), b7 = rot90<DIR>(csub(a5, a7));
-    v[0] = cadd(b0, b1); v[4] = csub(b0, b1); v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
-    v[1] = cadd(b4, b5); v[5] = csub(b4, b5); v[3] = cadd(b6, b7); v[7] = csub(b6, b7);
-}
 
 // np.fft.fftfreq(G)[a] as float32 (functions.py:75): integer frequency times 1/G in float64, then rounded.
 __device__ __forceinline__ float freq(int a, int G, double invG)
@@ -193,39 +168,6 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
 //   Z[k] = (X[k] + conj X[256-k]) + i w^-k (X[k] - conj X[256-k]),  z = unnormalised inverse FFT of Z.
 // Every global access of a wave is a contiguous 512-byte run.
 
-template <int DIR> __device__ __forceinline__ void fft4(float2 *v)
-{
-    float2 a0 = cadd(v[0], v[2]), a2 = csub(v[0], v[2]);
-    float2 a1 = cadd(v[1], v[3]), a3 = rot90<DIR>(csub(v[1], v[3]));
-    v[0] = cadd(a0, a1); v[2] = csub(a0, a1); v[1] = cadd(a2, a3); v[3] = csub(a2, a3);
-}
-
-// 256-point FFT of the values a wave holds as v[r] = element (lane + 64 r); result in the same form.
-// `buf` is the wave's 256-element LDS exchange buffer, `tw` the 512-entry twiddle table in LDS.
-template <int DIR>
-__device__ __forceinline__ void wave_fft256(float2 *v, float2 *buf, const float2 *tw, int j)
-{
-    fft4<DIR>(v);                                       // stage 1, Ns = 1: no twiddles
-#pragma unroll
-    for (int r = 0; r < 4; ++r) buf[4 * j + r] = v[r];
-#pragma unroll
-    for (int s = 1; s < 4; ++s) {                       // Ns = 4, 16, 64
-        const int Ns = 1 << (2 * s), k = j & (Ns - 1), step = 128 >> (2 * s);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = buf[j + 64 * r];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], twid<DIR>(tw[r * k * step]));
-        fft4<DIR>(v);
-        if (s < 3) {
-            __syncthreads();
-            const int j0 = ((j >> (2 * s)) << (2 * s + 2)) + k;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) buf[j0 + r * Ns] = v[r];
-        }
-    }
-}
-
 constexpr int ROWS_PER_WAVE = 4;
 
 __global__ void __launch_bounds__(FFT_BLOCK)
@@ -236,29 +178,15 @@ k_row_r2c512(const float *__restrict__ in, float2 *__restrict__ out, int pitch, 
     const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
     float2 *buf = bufs[w];
     for (int q = threadIdx.x; q < 512; q += FFT_BLOCK) tw[q] = twiddle[q];
+    __syncthreads();
     const int64_t row0 = ((int64_t)blockIdx.x * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
         const float2 *src = (const float2 *)(in + (row0 + rr) * 512);
         float2 v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = src[j + 64 * r];
-        __syncthreads();                                // twiddles in place / previous row's buffer reads done
         wave_fft256<-1>(v, buf, tw, j);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) buf[j + 64 * r] = v[r];
-        __syncthreads();
-        float2 *dst = out + (row0 + rr) * pitch;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = j + 64 * r;
-            const float2 zk = v[r], zp = buf[(256 - k) & 255];
-            const float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));      // (Z[k] + conj Z[256-k]) / 2
-            const float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));      // (Z[k] - conj Z[256-k]) / 2
-            const float2 t = cmul(tw[k], d);                                               // w^k d
-            dst[k] = make_float2(e.x + t.y, e.y - t.x);                                    // e - i t
-            if (k == 0) dst[256] = make_float2(zk.x - zk.y, 0.0f);
-        }
+        wave_r2c_split512(v, buf, tw, j, out + (row0 + rr) * pitch);
     }
 }
 
@@ -270,6 +198,7 @@ k_row_c2r512(const float2 *__restrict__ in, float *__restrict__ out, int pitch, 
     const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
     float2 *buf = bufs[w];
     for (int q = threadIdx.x; q < 512; q += FFT_BLOCK) tw[q] = twiddle[q];
+    __syncthreads();
     const int64_t row0 = ((int64_t)blockIdx.x * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
         const float2 *src = in + (row0 + rr) * pitch;
@@ -277,11 +206,11 @@ k_row_c2r512(const float2 *__restrict__ in, float *__restrict__ out, int pitch, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = src[j + 64 * r];
         float2 xn = (j == 0) ? src[256] : make_float2(0.0f, 0.0f);
-        __syncthreads();                                // twiddles in place / previous row's buffer reads done
+        wave_sync();
 #pragma unroll
         for (int r = 0; r < 4; ++r) buf[j + 64 * r] = x[r];
         if (j == 0) buf[256] = xn;
-        __syncthreads();
+        wave_sync();
         float2 v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -294,7 +223,6 @@ k_row_c2r512(const float2 *__restrict__ in, float *__restrict__ out, int pitch, 
             const float2 t = cmul(make_float2(wk.x, -wk.y), d);            // w^-k d
             v[r] = make_float2(e.x - t.y, e.y + t.x);                      // e + i t
         }
-        __syncthreads();
         wave_fft256<1>(v, buf, tw, j);
         float2 *dst = (float2 *)(out + (row0 + rr) * 512);
 #pragma unroll

@@ -104,7 +104,7 @@ size_t pm_sort_tmp_bytes(int64_t cap);
 hipError_t pm_launch_reorder(pm_ctx *c);
 hipError_t pm_settle_velocities(pm_ctx *c);     // must run before src is overwritten by a new sort
 hipError_t pm_launch_row_start(pm_ctx *c);
-hipError_t pm_launch_deposit(pm_ctx *c);
+hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum);
 hipError_t pm_launch_green(pm_ctx *c);
 bool pm_fft_custom_supported(int G);
 int pm_fft_pitch(int G);

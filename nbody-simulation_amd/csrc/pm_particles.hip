@@ -6,6 +6,7 @@
 // wrap, scale, fractional parts and weights in float64; this file is built with
 // -ffp-contract=off so no product is fused into an add.
 #include "pm_internal.hpp"
+#include "pm_fft_dev.hpp"
 
 namespace {
 
@@ -154,7 +155,16 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 // A piece starts at the first particle of a heavy cell, and at every multiple of HEAVY_PIECE that
 // has at least HEAVY_CELL particles of the same cell on either side (key[] is the sorted key
 // array, so slot r reads its neighbours' keys).
-constexpr uint32_t HEAVY_CELL = 16, HEAVY_PIECE = 2048;
+#ifndef PM_HEAVY_CELL
+#define PM_HEAVY_CELL 128
+#endif
+#ifndef PM_HEAVY_WAVES
+#define PM_HEAVY_WAVES 8
+#endif
+#ifndef PM_HEAVY_RUN
+#define PM_HEAVY_RUN 1024
+#endif
+constexpr uint32_t HEAVY_CELL = PM_HEAVY_CELL, HEAVY_PIECE = 2048;
 // Lists filled through atomic counters are split into shards, each with its own counter on its own
 // 128-byte line and its own region of the list, so that appends do not queue on one address.
 constexpr uint32_t PIECE_SHARDS = 64, ROW_SHARDS = 16, COUNTER_STRIDE = 32;
@@ -242,7 +252,7 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 //  * rows with a source run of more than HEAVY_RUN particles are left to k_deposit_heavy, where
 //    several waves walk contiguous slices of each run into their own LDS rows and the rows are
 //    added in wave order.
-constexpr uint32_t HEAVY_RUN = 1024;
+constexpr uint32_t HEAVY_RUN = PM_HEAVY_RUN;
 
 // One wave per listed piece: the part of the run of its first particle's cell up to the next
 // piece start.  Its eight corner sums (mass * wx * wy * wz, left
@@ -393,21 +403,64 @@ __device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uin
     return t;
 }
 
+// A summed row leaves the kernel either as G float32 densities (SPECTRUM = false) or, for G = 512,
+// already transformed along z: the wave packs the row into 256 complex numbers, runs the 256-point
+// FFT and writes the 257 values of the row's half spectrum (SPECTRUM = true).  The density mesh is
+// then never written or read; the bits are those of writing it and transforming it afterwards.
+template <bool SPECTRUM>
+__device__ __forceinline__ void emit_row(double *acc, const float2 *tw, float *__restrict__ density, float2 *__restrict__ spectrum,
+                                         uint32_t row, int G, int pitch)
+{
+    const int j = lane_id();
+    if constexpr (SPECTRUM) {
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = j + 64 * r;
+            v[r] = make_float2((float)acc[2 * n], (float)acc[2 * n + 1]);
+        }
+        float2 *buf = (float2 *)acc;                    // the row's LDS is free once every lane holds its part
+        pmfft::wave_fft256<-1>(v, buf, tw, j);
+        pmfft::wave_r2c_split512(v, buf, tw, j, spectrum + (size_t)row * pitch);
+    } else {
+        float *out = density + (size_t)row * G;
+        for (int c = j; c < G; c += 64) out[c] = (float)acc[c];
+    }
+}
+
+template <bool SPECTRUM>
+__device__ __forceinline__ void emit_empty_row(float *__restrict__ density, float2 *__restrict__ spectrum, uint32_t row, int G, int pitch)
+{
+    const int j = lane_id();
+    if constexpr (SPECTRUM) {
+        float2 *dst = spectrum + (size_t)row * pitch;
+        for (int c = j; c <= G / 2; c += 64) dst[c] = make_float2(0.0f, 0.0f);
+    } else {
+        float *out = density + (size_t)row * G;
+        for (int c = j; c < G; c += 64) out[c] = 0.0f;
+    }
+}
+
 // One wave per density row: the first pass of each of the four runs is requested before any is
 // processed, then the runs are walked in the order q = 0..3.
-template <typename TP>
+template <typename TP, bool SPECTRUM>
 __global__ void __launch_bounds__(BLOCK)
 k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
                const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
+               float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
                uint32_t *__restrict__ heavy_rows, uint32_t *__restrict__ heavy_count, pm_geom g)
 {
-    extern __shared__ double lds_rows[];
+    extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then 512 twiddles if SPECTRUM
     const int G = g.G;
     const uint32_t R = (uint32_t)G * (uint32_t)G;
     const uint32_t row = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    if (row >= R) return;                              // whole waves leave together; no barrier below
+    float2 *tw = (float2 *)(lds_rows + (size_t)(BLOCK / 64) * G);
+    if constexpr (SPECTRUM) {
+        for (int q = threadIdx.x; q < 512; q += BLOCK) tw[q] = twiddle[q];
+        __syncthreads();                                // the only block-wide barrier: before any wave leaves
+    }
+    if (row >= R) return;
     double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
-    float *out = density + (size_t)row * G;
     row_runs t = runs_of(rs, row, G);
     if (t.longest > HEAVY_RUN) {
         if (lane_id() == 0) {
@@ -417,7 +470,7 @@ k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ k
         return;
     }
     if (t.longest == 0) {
-        for (int c = lane_id(); c < G; c += 64) out[c] = 0.0f;
+        emit_empty_row<SPECTRUM>(density, spectrum, row, G, g.Ghp);
         return;
     }
     pass_t<TP> first[4];
@@ -426,22 +479,27 @@ k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ k
     for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) deposit_run(P, key, skip, pre, cap, t.beg[q], t.end[q], first[q], q & 1, q >> 1, g, acc);
-    for (int c = lane_id(); c < G; c += 64) out[c] = (float)acc[c];
+    pmfft::wave_sync();
+    emit_row<SPECTRUM>(acc, tw, density, spectrum, row, G, g.Ghp);
 }
 
 // Rows with a long run: a block of 4*S waves; wave w walks slice w/4 of run w%4 into its own LDS
 // row, and the rows are added in wave order.
-template <typename TP>
+template <typename TP, bool SPECTRUM>
 __global__ void __launch_bounds__(1024)
 k_deposit_heavy(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
                 const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
+                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
                 const uint32_t *__restrict__ heavy_rows, const uint32_t *__restrict__ heavy_count, pm_geom g)
 {
-    extern __shared__ double lds_rows[];
+    extern __shared__ double lds_rows[];                // one row of G doubles per wave, then 512 twiddles if SPECTRUM
     const int G = g.G;
     const int nw = blockDim.x >> 6, w = threadIdx.x >> 6;
     const int q = w & 3, slice = w >> 2, slices = nw >> 2;
     double *acc = lds_rows + (size_t)w * G;
+    float2 *tw = (float2 *)(lds_rows + (size_t)nw * G);
+    if constexpr (SPECTRUM)
+        for (int c = threadIdx.x; c < 512; c += blockDim.x) tw[c] = twiddle[c];
     // blocks s, s + ROW_SHARDS, ... serve shard s
     const uint32_t shard = blockIdx.x % ROW_SHARDS;
     const uint32_t cnt = heavy_count[shard * COUNTER_STRIDE];
@@ -458,13 +516,41 @@ k_deposit_heavy(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ 
         if (e2 > t.end[q]) e2 = t.end[q];
         deposit_run(P, key, skip, pre, cap, b, e2, load_pass(P, skip, b, e2), q & 1, q >> 1, g, acc);
         __syncthreads();
-        float *out = density + (size_t)row * G;
+        // column c of the block's rows, added in wave order, lands in row 0
         for (int c = threadIdx.x; c < G; c += blockDim.x) {
             double sum = 0.0;
             for (int v = 0; v < nw; ++v) sum += lds_rows[(size_t)v * G + c];
-            out[c] = (float)sum;
+            lds_rows[c] = sum;
         }
         __syncthreads();
+        if (w == 0) emit_row<SPECTRUM>(lds_rows, tw, density, spectrum, row, G, g.Ghp);
+        __syncthreads();
+    }
+}
+
+// The rows k_deposit_heavy<.., false> left in a scratch mesh as float32, transformed along z into the
+// half spectrum: one wave per listed row.
+__global__ void __launch_bounds__(BLOCK)
+k_heavy_rows_r2c(const float *__restrict__ rows, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
+                 const uint32_t *__restrict__ heavy_rows, const uint32_t *__restrict__ heavy_count, int G, int pitch)
+{
+    __shared__ float2 tw[512];
+    __shared__ float2 bufs[BLOCK / 64][256];
+    const int j = lane_id(), w = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < 512; q += BLOCK) tw[q] = twiddle[q];
+    __syncthreads();
+    const uint32_t shard = blockIdx.x % ROW_SHARDS;
+    const uint32_t cnt = heavy_count[shard * COUNTER_STRIDE];
+    heavy_rows += (size_t)shard * ((uint32_t)G * (uint32_t)G / ROW_SHARDS + 1);
+    const uint32_t waves = (gridDim.x / ROW_SHARDS) * (BLOCK / 64);
+    for (uint32_t e = (blockIdx.x / ROW_SHARDS) * (BLOCK / 64) + w; e < cnt; e += waves) {
+        const uint32_t row = heavy_rows[e];
+        const float2 *src = (const float2 *)(rows + (size_t)row * G);
+        float2 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = src[j + 64 * r];
+        pmfft::wave_fft256<-1>(v, bufs[w], tw, j);
+        pmfft::wave_r2c_split512(v, bufs[w], tw, j, spectrum + (size_t)row * pitch);
     }
 }
 
@@ -673,10 +759,10 @@ size_t pm_heavy_row_entries(int G) { return ((size_t)G * G / ROW_SHARDS + 1) * R
 static int heavy_waves(int G)
 {
     int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double))) & ~3;     // a multiple of 4: waves per run
-    return nw > 16 ? 16 : (nw < 4 ? 4 : nw);
+    return nw > PM_HEAVY_WAVES ? PM_HEAVY_WAVES : (nw < 4 ? 4 : nw);
 }
 
-template <typename TP>
+template <typename TP, bool SPECTRUM>
 static hipError_t deposit_dispatch(pm_ctx *c, const pm_prec<TP> *P)
 {
     const int G = c->g.G;
@@ -685,27 +771,36 @@ static hipError_t deposit_dispatch(pm_ctx *c, const pm_prec<TP> *P)
     if (e != hipSuccess) return e;
     k_heavy_pieces<TP><<<PIECE_SHARDS * 32, BLOCK, 0, c->stream>>>(P, c->key_out, c->piece_list, c->counters + PM_PIECE_COUNTERS,
                                                                  pm_piece_shard_cap(c->cap), c->pre, c->skip, c->n, c->cap, c->g);
-    const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double);
-    k_deposit_rows<TP><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
-        P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->heavy_rows, c->counters, c->g);
+    const size_t tw_bytes = SPECTRUM ? 512 * sizeof(float2) : 0;
+    const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double) + tw_bytes;
+    k_deposit_rows<TP, SPECTRUM><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
+        P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
     const int nw = heavy_waves(G);
     const size_t lds_heavy = (size_t)nw * G * sizeof(double);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[sizeof(TP) == 8]) {
-        e = hipFuncSetAttribute((const void *)k_deposit_heavy<TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // heavy rows always leave as float32 rows of the density mesh; in spectrum mode a small kernel transforms them
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute((const void *)k_deposit_heavy<TP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[sizeof(TP) == 8] = true;
+        attr_set = true;
     }
-    k_deposit_heavy<TP><<<512, nw * 64, lds_heavy, c->stream>>>(P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density,
-                                                                c->heavy_rows, c->counters, c->g);
+    k_deposit_heavy<TP, false><<<512, nw * 64, lds_heavy, c->stream>>>(P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density,
+                                                                       c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
+    if (SPECTRUM)
+        k_heavy_rows_r2c<<<ROW_SHARDS * 16, BLOCK, 0, c->stream>>>(c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, G, c->g.Ghp);
     return hipGetLastError();
 }
 
-hipError_t pm_launch_deposit(pm_ctx *c)
+// to_spectrum: leave the z-transformed rows in the half spectrum instead of the density mesh (G = 512 only)
+hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum)
 {
     int u = c->cur;
-    if (c->pos_f64) return deposit_dispatch<double>(c, c->pd[u]);
-    return deposit_dispatch<float>(c, c->pf[u]);
+    if (to_spectrum) {
+        if (c->pos_f64) return deposit_dispatch<double, true>(c, c->pd[u]);
+        return deposit_dispatch<float, true>(c, c->pf[u]);
+    }
+    if (c->pos_f64) return deposit_dispatch<double, false>(c, c->pd[u]);
+    return deposit_dispatch<float, false>(c, c->pf[u]);
 }
 
 template <typename TP, typename TV>

@@ -135,6 +135,26 @@ def test_fused_gradient_is_bit_identical(pm, golden):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
+def test_fused_step_512(pm):
+    """G = 512: the fused step (deposit emits z-transformed rows, gradient inside the gather) against
+    the stage-by-stage step, clustered input with heavy cells and heavy rows."""
+    n, G, L, dt = 400_000, 512, 10000, 0.005
+    rng = np.random.default_rng(9)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    pos[: n // 2] = (5000 + rng.normal(0, 40, (n // 2, 3))).astype(np.float32)
+    vel = rng.normal(0, 2000, (n, 3)).astype(np.float32)
+    mass = (rng.random(n) + 0.5).astype(np.float32) * 100
+    out = []
+    for fused in (False, True):
+        with pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused) as sim:
+            sim.step(dt, 3)
+            out.append((sim.positions(), sim.velocities()))
+    dx = np.abs(out[0][0].astype(np.float64) - out[1][0])
+    assert np.minimum(dx, L - dx).max() <= 1e-6 * L
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-6 * np.abs(out[0][1]).max()
+    print("fused == staged bitwise:", np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]))
+
+
 def test_cell_order_over_steps(pm, golden):
     """Cell order = stable sort by key of the storage order, which is the previous cell order."""
     g = golden("uniform_n10000_g32.npz")

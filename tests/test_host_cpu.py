@@ -48,3 +48,4 @@ def test_bench_workloads():
         assert pos.min() >= 0 and pos.max() <= 10000 and mass.dtype == np.float32
     b = bench.stage_bytes(100, 1000)
     assert sum(b.values()) == 64 * 100 + 80 * 1000
+    assert sum(bench.stage_bytes(100, 1000, fused=True).values()) == 64 * 100 + 80 * 1000
