@@ -30,7 +30,7 @@ extern "C" {
 typedef struct pm_ctx pm_ctx;
 
 /* error codes */
-enum { PM_OK = 0, PM_EINVAL = 1, PM_ENOMEM = 2, PM_EHIP = 3, PM_EFFT = 4, PM_ESTATE = 5 };
+enum { PM_OK = 0, PM_EINVAL = 1, PM_ENOMEM = 2, PM_EHIP = 3, PM_EFFT = 4, PM_ESTATE = 5, PM_ERANGE = 6 };
 
 /* host dtypes of particle arrays */
 enum { PM_F32 = 0, PM_F64 = 1 };
@@ -96,6 +96,22 @@ int pm_set_mesh(pm_ctx *ctx, int which, const float *in /* G*G*G */);
  * in cell order (cell (i,j,k) as functions.py:27-39 computes it), perm[r] =
  * its index in the caller's original order.  Ties keep storage order. */
 int pm_get_cell_keys(pm_ctx *ctx, int64_t *keys, int64_t *perm);
+
+/* compute_kinetic_energy(velocities, masses) and compute_potential_energy(positions, masses,
+ * potential, grid_size, box_size): functions.py:352-361, call sites main.py:65-66.  Uses the live
+ * particle state and the potential mesh the context holds (in pm_step's flow: positions after the
+ * drift, potential from before it, as the reference does).  Sums run in float64. */
+int pm_energies(pm_ctx *ctx, double *ke, double *pe);
+
+/* The nearest-grid-point branch (CIC_interpolation = False, main.py:9,40-41):
+ * NGP(positions, grid_size, box_size, masses): functions.py:11-16 -- float64 mesh, read with
+ * pm_get_mesh_f64(PM_MESH_DENSITY).  Returns PM_ERANGE where the reference raises IndexError (a
+ * float32 position that wraps to exactly box_size).
+ * force_NGP(potential_gradient, positions, grid_size, box_size): functions.py:92-97 -- the float32
+ * gradient meshes the context holds, at the particle's cell; result via pm_get_forces. */
+int pm_deposit_ngp(pm_ctx *ctx);
+int pm_forces_ngp(pm_ctx *ctx);
+int pm_get_mesh_f64(pm_ctx *ctx, int which, double *out /* G*G*G */);
 
 /* Accumulated milliseconds and call counts per stage since the last call
  * (needs PM_FLAG_TIMING); both arrays have PM_NSTAGES entries.  Synchronises. */

@@ -123,7 +123,7 @@ void pm_destroy(pm_ctx *c)
     hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->piece_list); hipFree(c->skip); hipFree(c->pre);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
-    hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage);
+    hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage); hipFree(c->diag); hipFree(c->density64);
     if (c->info) rocfft_execution_info_destroy(c->info);
     if (c->fwd) rocfft_plan_destroy(c->fwd);
     if (c->inv) rocfft_plan_destroy(c->inv);
@@ -159,6 +159,7 @@ static int create_impl(pm_ctx *c)
     for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
     TRY(dalloc(c, &c->spectrum, (size_t)G * G * c->g.Ghp));
     TRY(dalloc(c, &c->forces, 3 * cap));
+    TRY(dalloc(c, &c->diag, 2 * 1024 + 4));
     HIP_TRY(c, hipMalloc(&c->stage, cap * 32 + 16));
 
     std::call_once(g_fft_once, [] { rocfft_setup(); });
@@ -429,6 +430,62 @@ int pm_get_cell_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
         HIP_TRY(c, hipMemcpyAsync(perm, dp, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    return PM_OK;
+}
+
+int pm_energies(pm_ctx *c, double *ke, double *pe)
+{
+    TRY(need_particles(c));
+    if (!ke || !pe) return fail(c, PM_EINVAL, "NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *res = c->diag + 2 * 1024;
+    HIP_TRY(c, pm_launch_energies(c, res, res + 1));
+    double host[2] = {0.0, 0.0};
+    HIP_TRY(c, hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *ke = host[0]; *pe = host[1];
+    return PM_OK;
+}
+
+int pm_forces_ngp(pm_ctx *c)
+{
+    TRY(need_particles(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    stage_timer t(c, PM_STAGE_GATHER);
+    HIP_TRY(c, pm_launch_force_ngp(c));
+    c->have_forces = true;
+    return PM_OK;
+}
+
+int pm_deposit_ngp(pm_ctx *c)
+{
+    TRY(need_particles(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(dalloc(c, &c->density64, (size_t)c->g.M));
+    // the sort scratch (keys, src) is shared with the cloud-in-cell binning: settle what depends on it
+    HIP_TRY(c, pm_settle_velocities(c));
+    c->binned = false; c->keys_fresh = false;
+    uint32_t *bad = (uint32_t *)(c->diag + 2 * 1024 + 2);
+    HIP_TRY(c, hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->density64, 0, (size_t)c->g.M * sizeof(double), c->stream));
+    HIP_TRY(c, pm_launch_ngp_keys(c, bad));
+    HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
+    HIP_TRY(c, pm_launch_ngp_sum(c));
+    uint32_t h = 0;
+    HIP_TRY(c, hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h) return fail(c, PM_ERANGE, "NGP index out of range: a position wraps to exactly box_size (the reference raises IndexError here)");
+    return PM_OK;
+}
+
+int pm_get_mesh_f64(pm_ctx *c, int which, double *out)
+{
+    if (!c) return PM_EINVAL;
+    if (which != PM_MESH_DENSITY || !out) return fail(c, PM_EINVAL, "only the NGP density is a float64 mesh");
+    if (!c->density64) return fail(c, PM_ESTATE, "no float64 density: call pm_deposit_ngp first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->density64, (size_t)c->g.M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PM_OK;
 }
 

@@ -1,0 +1,228 @@
+// Diagnostics and the nearest-grid-point variants of the reference, for gfx950:
+// kinetic / potential energy (functions.py:352-361), force_NGP (functions.py:92-97) and the NGP
+// deposit (functions.py:11-16).  Built with -ffp-contract=off: the index formulas below must round
+// exactly like NumPy evaluates them in the positions' dtype.
+#include "pm_internal.hpp"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int RED_BLOCKS = 1024;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
+
+// (pos / box_size * grid_size).astype(int) % grid_size, evaluated in the positions' dtype
+// (functions.py:94 and :358); Python's % gives a result in [0, G).
+template <typename T>
+__device__ __forceinline__ int ngp_wrapped_index(T x, T L, T Gf, int G)
+{
+    T s = (x / L) * Gf;
+    long long t = (long long)s;                 // astype(int) truncates toward zero
+    int r = (int)(t % G);
+    return r < 0 ? r + G : r;
+}
+
+// np.remainder(x, L) for L > 0 in the positions' dtype (functions.py:13): may return exactly L.
+template <typename T> __device__ __forceinline__ T np_remainder(T x, T L)
+{
+    T r = (sizeof(T) == 4) ? (T)fmodf((float)x, (float)L) : (T)fmod((double)x, (double)L);
+    if (r != (T)0) {
+        if (r < (T)0) r += L;
+    } else {
+        r = (T)0;
+    }
+    return r;
+}
+
+// Deterministic sum: every thread adds its grid-stride sequence in order, a fixed butterfly and a
+// fixed order over the waves give the block's partial; k_reduce_final adds the partials in order.
+__device__ __forceinline__ void block_partial(double v, double *__restrict__ partial)
+{
+    __shared__ double wsum[BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < BLOCK / 64; ++w) s += wsum[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+// KE = 0.5 * sum(m * (vx^2 + vy^2 + vz^2)): the per-particle term in the dtype NumPy gives it
+// (float32 for float32 velocities), the sum in float64.
+template <typename TV>
+__global__ void __launch_bounds__(BLOCK)
+k_kinetic(const pm_prec<float> *__restrict__ Pf, const pm_prec<double> *__restrict__ Pd, const pm_vrec<TV> *__restrict__ V,
+          const uint32_t *__restrict__ vmap, int64_t n, double *__restrict__ partial)
+{
+    double acc = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * BLOCK) {
+        const float m = Pf ? Pf[r].m : Pd[r].m;
+        const pm_vrec<TV> v = V[vmap ? vmap[r] : r];
+        TV v2 = (v.x * v.x + v.y * v.y) + v.z * v.z;
+        acc += (sizeof(TV) == 4) ? (double)(m * (float)v2) : (double)m * (double)v2;
+    }
+    block_partial(acc, partial);
+}
+
+// PE = 0.5 * sum(m * phi[ngp cell]): float32 product, float64 sum.
+template <typename TP>
+__global__ void __launch_bounds__(BLOCK)
+k_potential_energy(const pm_prec<TP> *__restrict__ P, const float *__restrict__ phi, int64_t n, pm_geom g, double *__restrict__ partial)
+{
+    const int G = g.G;
+    const TP L = (TP)g.L, Gf = (TP)G;
+    double acc = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * BLOCK) {
+        const pm_prec<TP> p = P[r];
+        int i = ngp_wrapped_index<TP>(p.x, L, Gf, G), j = ngp_wrapped_index<TP>(p.y, L, Gf, G), k = ngp_wrapped_index<TP>(p.z, L, Gf, G);
+        acc += (double)(p.m * phi[((int64_t)i * G + j) * G + k]);
+    }
+    block_partial(acc, partial);
+}
+
+__global__ void k_reduce_final(const double *__restrict__ partial, int count, double scale, double *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int q = 0; q < count; ++q) s += partial[q];
+        *out = s * scale;
+    }
+}
+
+// force_NGP: the three gradient meshes at the particle's nearest-grid-point cell.
+template <typename TP>
+__global__ void k_force_ngp(const pm_prec<TP> *__restrict__ P, const float *__restrict__ gx, const float *__restrict__ gy,
+                            const float *__restrict__ gz, float *__restrict__ forces, int64_t n, pm_geom g)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int G = g.G;
+    const TP L = (TP)g.L, Gf = (TP)G;
+    const pm_prec<TP> p = P[r];
+    int i = ngp_wrapped_index<TP>(p.x, L, Gf, G), j = ngp_wrapped_index<TP>(p.y, L, Gf, G), k = ngp_wrapped_index<TP>(p.z, L, Gf, G);
+    int64_t q = ((int64_t)i * G + j) * G + k;
+    forces[3 * r] = gx[q]; forces[3 * r + 1] = gy[q]; forces[3 * r + 2] = gz[q];
+}
+
+// NGP deposit keys: floor((pos % L) / L * G) per axis in the positions' dtype (functions.py:13-14).
+// An index that reaches G (the float32 remainder can return exactly L) is out of range in the
+// reference (IndexError): flagged, and folded to G-1 so the sort stays in range.
+template <typename TP>
+__global__ void k_ngp_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restrict__ key, int64_t n, pm_geom g, uint32_t *__restrict__ bad)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int G = g.G;
+    const TP L = (TP)g.L, Gf = (TP)G;
+    const pm_prec<TP> p = P[r];
+    TP c[3] = {p.x, p.y, p.z};
+    int idx[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        TP s = (np_remainder<TP>(c[a], L) / L) * Gf;
+        int t = (int)floor((double)s);
+        if (t >= G || t < 0) { atomicOr(bad, 1u); t = t < 0 ? 0 : G - 1; }
+        idx[a] = t;
+    }
+    key[r] = (uint32_t)(((int64_t)idx[0] * G + idx[1]) * G + idx[2]);
+}
+
+// np.add.at(density, cell, masses) with a float64 mesh: after a stable sort by cell the masses of a
+// cell are one run (slot src[r] of the particle array); the thread of the run's first element adds
+// them in order, runs of more than 64 by its whole wave (stride-64 partial sums, fixed butterfly).
+template <typename TP>
+__global__ void __launch_bounds__(BLOCK)
+k_ngp_sum(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ src, int64_t n,
+          double *__restrict__ density)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    bool head = r < n && (r == 0 || key[r - 1] != key[r]);
+    int64_t end = r;
+    uint32_t k0 = head ? key[r] : 0u;
+    if (head) {
+        // first index past the run: gallop, then bisect
+        int64_t inside = r, step = 1, outside = n;
+        while (inside + step < n) {
+            if (key[inside + step] == k0) { inside += step; step <<= 1; }
+            else { outside = inside + step; break; }
+        }
+        while (outside - inside > 1) {
+            int64_t mid = (inside + outside) >> 1;
+            if (key[mid] == k0) inside = mid; else outside = mid;
+        }
+        end = outside;
+    }
+    int64_t len = end - r;
+    if (head && len <= 64) {
+        double s = 0.0;
+        for (int64_t q = r; q < end; ++q) s += (double)P[src[q]].m;
+        density[k0] = s;
+    }
+    unsigned long long big = __ballot(head && len > 64);
+    while (big) {
+        int l = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        int64_t b = __shfl(r, l), e = __shfl(end, l);
+        double part = 0.0;
+        for (int64_t q = b + lane_id(); q < e; q += 64) part += (double)P[src[q]].m;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane_id() == l) density[k0] = part;
+    }
+}
+
+}  // namespace
+
+// ke and pe are two doubles in device memory (c->diag + 2*RED_BLOCKS ...); the caller copies them out.
+hipError_t pm_launch_energies(pm_ctx *c, double *d_ke, double *d_pe)
+{
+    const int64_t n = c->n;
+    double *part_k = c->diag, *part_p = c->diag + RED_BLOCKS;
+    int blocks = (int)((n + BLOCK - 1) / BLOCK);
+    if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const int u = c->cur;
+    const uint32_t *vmap = c->v_stale ? c->src : nullptr;
+    const pm_prec<float> *pf = c->pos_f64 ? nullptr : c->pf[u];
+    const pm_prec<double> *pd = c->pos_f64 ? c->pd[u] : nullptr;
+    if (c->vel_f64) k_kinetic<double><<<blocks, BLOCK, 0, c->stream>>>(pf, pd, c->vd[c->vcur], vmap, n, part_k);
+    else k_kinetic<float><<<blocks, BLOCK, 0, c->stream>>>(pf, pd, c->vf[c->vcur], vmap, n, part_k);
+    if (c->pos_f64) k_potential_energy<double><<<blocks, BLOCK, 0, c->stream>>>(c->pd[u], c->potential, n, c->g, part_p);
+    else k_potential_energy<float><<<blocks, BLOCK, 0, c->stream>>>(c->pf[u], c->potential, n, c->g, part_p);
+    k_reduce_final<<<1, 64, 0, c->stream>>>(part_k, blocks, 0.5, d_ke);
+    k_reduce_final<<<1, 64, 0, c->stream>>>(part_p, blocks, 0.5, d_pe);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_force_ngp(pm_ctx *c)
+{
+    if (c->n == 0) return hipSuccess;
+    const int u = c->cur;
+    if (c->pos_f64) k_force_ngp<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pd[u], c->grad[0], c->grad[1], c->grad[2], c->forces, c->n, c->g);
+    else k_force_ngp<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pf[u], c->grad[0], c->grad[1], c->grad[2], c->forces, c->n, c->g);
+    return hipGetLastError();
+}
+
+// keys -> key_in; `bad` is one device word, set when an index is out of range
+hipError_t pm_launch_ngp_keys(pm_ctx *c, uint32_t *bad)
+{
+    if (c->n == 0) return hipSuccess;
+    const int u = c->cur;
+    if (c->pos_f64) k_ngp_keys<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pd[u], c->key_in, c->n, c->g, bad);
+    else k_ngp_keys<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pf[u], c->key_in, c->n, c->g, bad);
+    return hipGetLastError();
+}
+
+// after pm_sort_pairs: key_out sorted, src = storage slot of each sorted element
+hipError_t pm_launch_ngp_sum(pm_ctx *c)
+{
+    if (c->n == 0) return hipSuccess;
+    const int u = c->cur;
+    if (c->pos_f64) k_ngp_sum<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pd[u], c->key_out, c->src, c->n, c->density64);
+    else k_ngp_sum<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pf[u], c->key_out, c->src, c->n, c->density64);
+    return hipGetLastError();
+}

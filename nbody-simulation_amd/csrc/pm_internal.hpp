@@ -78,6 +78,8 @@ struct pm_ctx {
     void *fft_work = nullptr;
     size_t fft_work_bytes = 0;
 
+    double *density64 = nullptr;        // float64 mesh of the NGP deposit (allocated on first use)
+    double *diag = nullptr;             // reduction partials and results of the energy diagnostics
     float *forces = nullptr;            // (n,3) AoS in storage order
     void *stage = nullptr;              // staging for host copies: cap * 32 bytes
 
@@ -116,3 +118,7 @@ hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_for
 hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos);
 hipError_t pm_launch_export_forces(pm_ctx *c, float *aos);
 hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm);
+hipError_t pm_launch_energies(pm_ctx *c, double *d_ke, double *d_pe);
+hipError_t pm_launch_force_ngp(pm_ctx *c);
+hipError_t pm_launch_ngp_keys(pm_ctx *c, uint32_t *bad);
+hipError_t pm_launch_ngp_sum(pm_ctx *c);

@@ -34,6 +34,10 @@ SIGNATURES = {
     "pm_get_mesh": (_int, [_c_p, _int, _c_p]),
     "pm_set_mesh": (_int, [_c_p, _int, _c_p]),
     "pm_get_cell_keys": (_int, [_c_p, _c_p, _c_p]),
+    "pm_energies": (_int, [_c_p, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
+    "pm_deposit_ngp": (_int, [_c_p]),
+    "pm_forces_ngp": (_int, [_c_p]),
+    "pm_get_mesh_f64": (_int, [_c_p, _int, _c_p]),
     "pm_stage_times": (_int, [_c_p, _c_p, _c_p]),
     "pm_set_flags": (_int, [_c_p, ctypes.c_uint]),
     "pm_synchronize": (_int, [_c_p]),
@@ -63,10 +67,16 @@ def load():
     return _lib
 
 
+PM_ERANGE = 6
+
+
 def check(ctx, rc):
     if rc != 0:
         msg = load().pm_last_error(ctx)
-        raise PMError(f"libpm error {rc}: {msg.decode() if msg else '?'}")
+        text = f"libpm error {rc}: {msg.decode() if msg else '?'}"
+        if rc == PM_ERANGE:
+            raise IndexError(text)          # what the reference's NumPy indexing raises
+        raise PMError(text)
 
 
 def ptr(a):

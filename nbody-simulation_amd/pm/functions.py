@@ -17,7 +17,8 @@ import numpy as np
 from . import _lib as L
 from .simulation import Simulation
 
-__all__ = ["CIC", "compute_potential", "gradient", "force_CIC", "kick_drift", "release"]
+__all__ = ["CIC", "NGP", "compute_potential", "gradient", "force_CIC", "force_NGP", "kick_drift",
+           "compute_kinetic_energy", "compute_potential_energy", "import_galaxy", "release"]
 
 _engines = {}
 
@@ -87,3 +88,69 @@ def kick_drift(potential_gradient, positions, velocities, grid_size, box_size, d
     sim.set_particles(positions, velocities, None)
     sim.gather_kick_drift(dt)
     return sim.positions(), sim.velocities()
+
+
+def NGP(positions: np.ndarray, grid_size: int, box_size: float, masses: np.ndarray) -> np.ndarray:
+    """Nearest-grid-point mass histogram -> (G,G,G) float64 (functions.py:11-16).  Raises IndexError
+    where the reference does: a float32 position that wraps to exactly box_size."""
+    sim = _engine(grid_size, box_size, len(positions))
+    sim.set_particles(positions, None, masses)
+    sim.deposit_ngp()
+    return sim.density_f64()
+
+
+def force_NGP(potential_gradient, positions: np.ndarray, grid_size: int, box_size: float) -> np.ndarray:
+    """The gradient meshes at each particle's nearest-grid-point cell -> (N,3) (functions.py:92-97).
+    float32 gradient meshes only (what np.gradient of a float32 potential gives)."""
+    grads = [np.asarray(a) for a in potential_gradient]
+    if any(a.dtype != np.float32 for a in grads):
+        raise NotImplementedError("force_NGP on the GPU takes float32 gradient meshes")
+    sim = _engine(grid_size, box_size, len(positions))
+    for which, a in zip((L.MESH_GX, L.MESH_GY, L.MESH_GZ), grads):
+        sim.set_mesh(which, a)
+    sim.set_particles(positions, None, None)
+    sim.compute_forces_ngp()
+    return sim.forces()
+
+
+def compute_kinetic_energy(velocities, masses):
+    """0.5 * sum(m * |v|^2) (functions.py:352-354), summed in float64 on the GPU."""
+    velocities = np.asarray(velocities)
+    sim = _engine(2, 1.0, len(velocities))
+    sim.set_particles(np.zeros((len(velocities), 3), np.float32), velocities, masses)
+    return sim.energies()[0]
+
+
+def compute_potential_energy(positions, masses, potential, grid_size, box_size):
+    """0.5 * sum(m * potential[nearest cell]) (functions.py:356-361), summed in float64 on the GPU."""
+    sim = _engine(grid_size, box_size, len(positions))
+    sim.set_mesh(L.MESH_POTENTIAL, potential)
+    sim.set_particles(positions, None, masses)
+    return sim.energies()[1]
+
+
+def import_galaxy(path1, path2=None, separation=1.0, direction=(1, 0, 0), velocity=(0, 0, 0)):
+    """Load one or two galaxy .npz files (keys positions, velocities, masses, labels; float64 on disk)
+    as the reference does (functions.py:303-348): float32 on load; the second galaxy is shifted so that
+    its centre of mass sits `separation` along `direction` from the first one's, and the relative
+    `velocity` is split between the two for zero total momentum.  Host-side set-up: plain NumPy.
+
+    Returns (positions, velocities, masses) for one file, (positions, velocities, masses, labels) for two;
+    with two files positions and velocities come out float64, as in the reference."""
+    def read(path):
+        with np.load(path) as z:
+            return [z[k].astype(np.float32) for k in ("positions", "velocities", "masses")] + [z["labels"]]
+
+    xa, va, ma, la = read(path1)
+    if path2 is None:
+        return xa, va, ma
+    xb, vb, mb, lb = read(path2)
+    centre = lambda x, m: (m[:, None] * x).sum(0) / m.sum()      # float32 centre of mass
+    axis = np.asarray(direction, float)
+    axis /= np.linalg.norm(axis)
+    xb = xb + ((centre(xa, ma) + axis * float(separation)) - centre(xb, mb))
+    total_a, total_b = np.sum(ma), np.sum(mb)
+    rel = np.asarray(velocity)
+    va = va + np.asarray(-(total_b / (total_a + total_b)) * rel)
+    vb = vb + np.asarray((total_a / (total_a + total_b)) * rel)
+    return np.vstack((xa, xb)), np.vstack((va, vb)), np.concatenate((ma, mb)), np.concatenate((la, lb))

@@ -76,6 +76,23 @@ class Simulation:
     def step(self, dt, n=1):
         self._ck(self.lib.pm_step(self.ctx, float(dt), int(n)))
 
+    def energies(self):
+        """(KE, PE) of functions.py:352-361 on the live state and the held potential mesh."""
+        ke, pe = L._dbl(), L._dbl()
+        self._ck(self.lib.pm_energies(self.ctx, ke, pe))
+        return ke.value, pe.value
+
+    def deposit_ngp(self):
+        self._ck(self.lib.pm_deposit_ngp(self.ctx))
+
+    def density_f64(self):
+        out = np.empty((self.grid_size,) * 3, np.float64)
+        self._ck(self.lib.pm_get_mesh_f64(self.ctx, L.MESH_DENSITY, L.ptr(out)))
+        return out
+
+    def compute_forces_ngp(self):
+        self._ck(self.lib.pm_forces_ngp(self.ctx))
+
     def synchronize(self):
         self._ck(self.lib.pm_synchronize(self.ctx))
 

@@ -297,6 +297,52 @@ def test_deposit_is_bitwise_reproducible(pm):
     assert_density(out[0], O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
 
 
+def test_energies(pm, golden):
+    """KE / PE every 10th step as main.py:64-67: post-drift positions, pre-drift potential."""
+    for name, tol in (("uniform_n10000_g32.npz", 1e-5), ("c1mini_g50.npz", 1e-5)):
+        g = golden(name)
+        G, L, dt, K = int(g["G"]), int(g["L"]), float(g["dt"]), int(g["K"])
+        with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"]) as sim:
+            for step in range(K):
+                sim.step(dt)
+                if f"s{step}_KE" in g:
+                    ke, pe = sim.energies()
+                    assert abs(ke - g[f"s{step}_KE"]) <= tol * abs(g[f"s{step}_KE"]), (name, step)
+                    assert abs(pe - g[f"s{step}_PE"]) <= tol * abs(g[f"s{step}_PE"]), (name, step)
+    # the stand-alone functions on the reference's own inputs
+    from pm import functions as F
+    g = golden("c1mini_g50.npz")
+    ke = F.compute_kinetic_energy(g["vel0"], g["mass"])
+    assert abs(ke - O.compute_kinetic_energy(g["vel0"], g["mass"])) <= 1e-12 * abs(ke)      # float64 velocities
+    x32 = g["x1"]
+    pe = F.compute_potential_energy(x32, g["mass"], g["s0_potential"], int(g["G"]), int(g["L"]))
+    assert abs(pe - O.compute_potential_energy(x32, g["mass"], g["s0_potential"], int(g["G"]), int(g["L"]))) <= 1e-5 * abs(pe)
+    F.release()
+
+
+def test_ngp_variants(pm, golden):
+    from pm import functions as F
+    g = golden("uniform_n10000_g32.npz")
+    G, L = int(g["G"]), int(g["L"])
+    d = F.NGP(g["pos0"], G, L, g["mass"])
+    assert d.dtype == np.float64 and np.array_equal(d, g["ngp_density"])
+    f = F.force_NGP((g["s0_gx"], g["s0_gy"], g["s0_gz"]), g["pos0"], G, L)
+    assert f.dtype == np.float32 and np.array_equal(f, g["ngp_forces"])
+    # a clump: long runs of one cell
+    rng = np.random.default_rng(4)
+    pos = (rng.random((50000, 3)) * L).astype(np.float32)
+    pos[:30000] = (7000 + rng.random((30000, 3)) * 100).astype(np.float32)
+    mass = (rng.random(50000) + 0.5).astype(np.float32)
+    assert np.allclose(F.NGP(pos, G, L, mass), O.NGP(pos, G, L, mass), rtol=1e-12, atol=0)
+    # the reference raises IndexError when the float32 wrap returns exactly box_size
+    bad = np.array([[-1e-9, 5.0, 5.0]], np.float32)
+    with pytest.raises(IndexError):
+        O.NGP(bad, G, L, np.ones(1, np.float32))
+    with pytest.raises(IndexError):
+        F.NGP(bad, G, L, np.ones(1, np.float32))
+    F.release()
+
+
 def test_errors(pm):
     lib = pm.load()
     assert not lib.pm_create(1, 1.0, 10, 0, 0)
