@@ -97,6 +97,29 @@ def stage_bytes(n, m, fused=False):
             "gradient": 16 * m, "gather": 48 * n + 12 * m}
 
 
+# kernels that make up each timed stage (substrings of the names rocprofv3 reports)
+STAGE_KERNELS = {"bin": ["rocprim", "k_reorder", "k_row_start", "k_cell_keys"],
+                 "deposit": ["k_heavy_pieces", "k_deposit_rows", "k_deposit_heavy", "k_heavy_rows_r2c"],
+                 "fft_fwd": ["k_row_r2c512", "k_col_fft512<-1, false>"], "green": ["k_col_fft512<-1, true>", "k_green"],
+                 "fft_inv": ["k_col_fft512<1, false>", "k_row_c2r512"], "gradient": ["k_gradient"], "gather": ["k_gather"]}
+
+
+def measured_traffic(stage):
+    """HBM bytes per step of a stage's kernels, from the committed rocprofv3 counter passes of this same
+    workload (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units,
+    FETCH_SIZE doubled for gfx950's half-counted wide reads).  None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        per_kernel = json.load(f)["kernels"]
+    total = 0.0
+    for name, v in per_kernel.items():
+        if any(sub in name for sub in STAGE_KERNELS[stage]):
+            total += v["read_bytes_per_step"] + v["write_bytes_per_step"]
+    return total or None
+
+
 def cpu_baseline(pos, vel, mass, G, L, dt):
     """One step of the CPU oracle on the same workload, single thread."""
     from oracle import pm_oracle as O
@@ -187,7 +210,8 @@ def main():
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "fused_gradient": fused,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBPS,
+                         "traffic": measured_traffic(dom) if (args.workload == "two_galaxy" and n == 16_777_216 and G == 512) else None,
                          "algorithmic_bytes_per_launch": b[dom], "ms_per_launch": per[dom]},
             "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved": b_step / (ms_step * 1e-3) / 1e9,
                               "unit": "GB/s", "frac": b_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
