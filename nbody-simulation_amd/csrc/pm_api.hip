@@ -119,6 +119,7 @@ void pm_destroy(pm_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
+    hipFree(c->frac);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
     hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->piece_list); hipFree(c->skip); hipFree(c->pre);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
@@ -143,6 +144,7 @@ static int create_impl(pm_ctx *c)
     for (int s = 0; s < PM_NSTAGES; ++s)
         for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
 
+    TRY(dalloc(c, &c->frac, cap));
     TRY(dalloc(c, &c->key_in, cap));
     TRY(dalloc(c, &c->key_out, cap));
     TRY(dalloc(c, &c->src, cap));

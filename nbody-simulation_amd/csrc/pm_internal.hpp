@@ -28,6 +28,8 @@ struct pm_geom {
 template <typename T> struct pm_prec;
 template <> struct alignas(16) pm_prec<float> { float x, y, z, m; };
 template <> struct alignas(16) pm_prec<double> { double x, y, z; float m; float pad; };
+// What the deposit reads of a particle besides its cell key: offsets inside the cell and the mass.
+struct alignas(16) pm_frac { float dx, dy, dz, m; };
 template <typename T> struct pm_vrec;
 template <> struct alignas(16) pm_vrec<float> { float x, y, z; uint32_t id; };
 template <> struct alignas(16) pm_vrec<double> { double x, y, z; uint32_t id; uint32_t pad; };
@@ -50,6 +52,7 @@ struct pm_ctx {
     pm_prec<double> *pd[2] = {};
     pm_vrec<float> *vf[2] = {};
     pm_vrec<double> *vd[2] = {};
+    pm_frac *frac = nullptr;    // fraction records of the live set, written by the reorder pass
     bool pos_f64 = false;       // live positions are in pd[]
     bool pos_in_f64 = false;    // dtype given to pm_set_particles
     bool vel_f64 = false;

@@ -147,7 +147,10 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 }
 
 // Cell order -> storage order.  Slot r of the new storage takes the position record of old slot
-// src[r].  The velocity records are not moved here: the gather, which reads and writes every one of
+// src[r] and gets a fraction record {dx, dy, dz, mass} -- the particle's offsets inside its cell
+// (functions.py:41-43, computed in float64 and rounded to float32 once) -- which is all the deposit
+// needs besides the cell key, so that the wrap / scale / floor arithmetic runs once per particle
+// here and not once per visit there.  The velocity records are not moved here: the gather, which reads and writes every one of
 // them anyway, reads record src[r] and writes it to slot r (k_move_v does it when no gather follows).
 //
 // The same pass prepares the deposit's handling of "heavy" cells (more than HEAVY_CELL
@@ -187,14 +190,18 @@ __global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__res
 
 template <typename TP>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
-                          const uint32_t *__restrict__ src, const uint32_t *__restrict__ key, uint32_t *__restrict__ skip,
-                          uint32_t *__restrict__ piece_list, uint32_t *__restrict__ piece_count, uint32_t shard_cap, int64_t n)
+                          pm_frac *__restrict__ F, const uint32_t *__restrict__ src, const uint32_t *__restrict__ key,
+                          uint32_t *__restrict__ skip, uint32_t *__restrict__ piece_list, uint32_t *__restrict__ piece_count,
+                          uint32_t shard_cap, int64_t n, pm_geom g)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     bool piece = false;
     if (r < n) {
         int64_t s = src[r];
-        Pout[r] = Pin[s];
+        const pm_prec<TP> rec = Pin[s];
+        Pout[r] = rec;
+        const cell_t c = locate(rec, g);
+        F[r] = pm_frac{(float)c.dx, (float)c.dy, (float)c.dz, rec.m};
         skip[r] = 0u;
         uint32_t kcur = key[r];
         bool head = (r == 0) || key[r - 1] != kcur;
@@ -254,15 +261,24 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 //    added in wave order.
 constexpr uint32_t HEAVY_RUN = PM_HEAVY_RUN;
 
+// The eight corner masses of a fraction record, mass * wx * wy * wz left to right (functions.py:61-68),
+// q = di + 2*dj + 4*dk; weights in float64 from the float32 offsets.
+__device__ __forceinline__ void corner_masses(const pm_frac &f, double w[8])
+{
+    const double dx = (double)f.dx, dy = (double)f.dy, dz = (double)f.dz, mm = (double)f.m;
+    const double mx[2] = {mm * (1.0 - dx), mm * dx};
+    const double wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = mx[q & 1] * wy[(q >> 1) & 1] * wz[q >> 2];
+}
+
 // One wave per listed piece: the part of the run of its first particle's cell up to the next
-// piece start.  Its eight corner sums (mass * wx * wy * wz, left
-// to right, functions.py:61-68; q = di + 2*dj + 4*dk) go to pre[q*cap + first]; skip[] gets, for
-// every particle of the piece, the index one past the piece (the first one also SKIP_HEAD).
-template <typename TP>
+// piece start.  Its eight corner sums go to pre[q*cap + first]; skip[] gets, for every particle of
+// the piece, the index one past the piece (the first one also SKIP_HEAD).
 __global__ void __launch_bounds__(BLOCK)
-k_heavy_pieces(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ piece_list,
+k_heavy_pieces(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ piece_list,
                const uint32_t *__restrict__ piece_count, uint32_t shard_cap, double *__restrict__ pre,
-               uint32_t *__restrict__ skip, int64_t n, int64_t cap, pm_geom g)
+               uint32_t *__restrict__ skip, int64_t n, int64_t cap)
 {
     // blocks s, s + PIECE_SHARDS, ... serve shard s
     const uint32_t shard = blockIdx.x % PIECE_SHARDS;
@@ -280,13 +296,10 @@ k_heavy_pieces(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ k
         uint32_t mine = 0;
         for (int64_t r = (int64_t)first + lane_id(); r < bound; r += 64) {
             if (key[r] != k0) break;                      // cell order: the run has ended
-            pm_prec<TP> p = P[r];
-            cell_t c = locate(p, g);
-            double mm = (double)p.m;
-            double mx[2] = {mm * (1.0 - c.dx), mm * c.dx};
-            double wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
+            double w[8];
+            corner_masses(F[r], w);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += mx[q & 1] * wy[(q >> 1) & 1] * wz[q >> 2];
+            for (int q = 0; q < 8; ++q) acc[q] += w[q];
             ++mine;
         }
 #pragma unroll
@@ -313,15 +326,14 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 }
 
 // What one lane holds of a 64-particle pass over a run.
-template <typename TP> struct pass_t { uint32_t sk; pm_prec<TP> p; };
+struct pass_t { uint32_t sk, key; pm_frac f; };
 
-template <typename TP>
-__device__ __forceinline__ pass_t<TP> load_pass(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ skip,
-                                               uint32_t base, uint32_t end)
+__device__ __forceinline__ pass_t load_pass(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
+                                            const uint32_t *__restrict__ skip, uint32_t base, uint32_t end)
 {
-    pass_t<TP> t{};
+    pass_t t{};
     const uint32_t r = base + lane_id();
-    if (r < end) { t.sk = skip[r]; t.p = P[r]; }
+    if (r < end) { t.sk = skip[r]; t.key = key[r]; t.f = F[r]; }
     return t;
 }
 
@@ -333,13 +345,10 @@ __device__ __forceinline__ pass_t<TP> load_pass(const pm_prec<TP> *__restrict__ 
 // which adds the sums k_heavy_pieces left in pre[]; when a pass ends inside a piece the walk
 // continues after it.  `cur` is the first pass, already loaded; the next pass is requested
 // before the current one is processed.
-template <typename TP>
-__device__ __forceinline__ void deposit_run(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key,
+__device__ __forceinline__ void deposit_run(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
                                             const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
-                                            uint32_t beg, uint32_t end, pass_t<TP> cur, int di, int dj, const pm_geom &g,
-                                            double *acc)
+                                            uint32_t beg, uint32_t end, pass_t cur, int di, int dj, int G, double *acc)
 {
-    const int G = g.G;
     const int lane = lane_id();
     const double *pre_lo = pre + (int64_t)(di + 2 * dj) * cap, *pre_hi = pre + (int64_t)(di + 2 * dj + 4) * cap;
     uint32_t base = beg;
@@ -347,20 +356,21 @@ __device__ __forceinline__ void deposit_run(const pm_prec<TP> *__restrict__ P, c
         const uint32_t r = base + lane;
         const bool live = r < end;
         const uint32_t sk = cur.sk;
-        const pm_prec<TP> p = cur.p;
+        const pm_frac f = cur.f;
+        const int kc = (int)(cur.key % (uint32_t)G);
         const uint32_t sk_last = __shfl(sk, 63) & ~SKIP_HEAD;   // 0 unless the pass ends inside a piece
         const uint32_t next = (sk_last != 0u) ? sk_last : base + 64;
-        if (next < end) cur = load_pass(P, skip, next, end);    // in flight while this pass is summed
+        if (next < end) cur = load_pass(F, key, skip, next, end);   // in flight while this pass is summed
         int k = 0x7fffffff - lane;                              // idle lanes: distinct, never equal to a cell
         double lo = 0.0, hi = 0.0;
         bool add = false;
         if (live && sk == 0u) {
-            cell_t c = locate(p, g);
-            double w = (double)p.m * (di ? c.dx : 1.0 - c.dx) * (dj ? c.dy : 1.0 - c.dy);
-            k = c.k; lo = w * (1.0 - c.dz); hi = w * c.dz;
+            const double dx = (double)f.dx, dy = (double)f.dy, dz = (double)f.dz;
+            const double w = (double)f.m * (di ? dx : 1.0 - dx) * (dj ? dy : 1.0 - dy);
+            k = kc; lo = w * (1.0 - dz); hi = w * dz;
             add = true;
         } else if (sk & SKIP_HEAD) {
-            k = (int)(key[r] % (uint32_t)G);
+            k = kc;
             lo = pre_lo[r]; hi = pre_hi[r];
             add = true;
         }
@@ -443,9 +453,9 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
 
 // One wave per density row: the first pass of each of the four runs is requested before any is
 // processed, then the runs are walked in the order q = 0..3.
-template <typename TP, bool SPECTRUM>
+template <bool SPECTRUM>
 __global__ void __launch_bounds__(BLOCK)
-k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
+k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
                const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
                uint32_t *__restrict__ heavy_rows, uint32_t *__restrict__ heavy_count, pm_geom g)
@@ -473,21 +483,21 @@ k_deposit_rows(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ k
         emit_empty_row<SPECTRUM>(density, spectrum, row, G, g.Ghp);
         return;
     }
-    pass_t<TP> first[4];
+    pass_t first[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) first[q] = load_pass(P, skip, t.beg[q], t.end[q]);
+    for (int q = 0; q < 4; ++q) first[q] = load_pass(F, key, skip, t.beg[q], t.end[q]);
     for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) deposit_run(P, key, skip, pre, cap, t.beg[q], t.end[q], first[q], q & 1, q >> 1, g, acc);
+    for (int q = 0; q < 4; ++q) deposit_run(F, key, skip, pre, cap, t.beg[q], t.end[q], first[q], q & 1, q >> 1, G, acc);
     pmfft::wave_sync();
     emit_row<SPECTRUM>(acc, tw, density, spectrum, row, G, g.Ghp);
 }
 
 // Rows with a long run: a block of 4*S waves; wave w walks slice w/4 of run w%4 into its own LDS
 // row, and the rows are added in wave order.
-template <typename TP, bool SPECTRUM>
+template <bool SPECTRUM>
 __global__ void __launch_bounds__(1024)
-k_deposit_heavy(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
+k_deposit_heavy(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
                 const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
                 float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
                 const uint32_t *__restrict__ heavy_rows, const uint32_t *__restrict__ heavy_count, pm_geom g)
@@ -514,7 +524,7 @@ k_deposit_heavy(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ 
         uint32_t b = t.beg[q] + (uint32_t)slice * sl, e2 = b + sl;
         if (b > t.end[q]) b = t.end[q];
         if (e2 > t.end[q]) e2 = t.end[q];
-        deposit_run(P, key, skip, pre, cap, b, e2, load_pass(P, skip, b, e2), q & 1, q >> 1, g, acc);
+        deposit_run(F, key, skip, pre, cap, b, e2, load_pass(F, key, skip, b, e2), q & 1, q >> 1, G, acc);
         __syncthreads();
         // column c of the block's rows, added in wave order, lands in row 0
         for (int c = threadIdx.x; c < G; c += blockDim.x) {
@@ -731,8 +741,8 @@ hipError_t pm_launch_reorder(pm_ctx *c)
     if (n == 0) return hipSuccess;
     int u = c->cur, w = 1 - u;
     const uint32_t cap = pm_piece_shard_cap(c->cap);
-    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n);
-    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n);
+    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
+    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
     c->cur = w;
     c->v_stale = true;
     return hipGetLastError();
@@ -762,30 +772,30 @@ static int heavy_waves(int G)
     return nw > PM_HEAVY_WAVES ? PM_HEAVY_WAVES : (nw < 4 ? 4 : nw);
 }
 
-template <typename TP, bool SPECTRUM>
-static hipError_t deposit_dispatch(pm_ctx *c, const pm_prec<TP> *P)
+template <bool SPECTRUM>
+static hipError_t deposit_dispatch(pm_ctx *c)
 {
     const int G = c->g.G;
     const uint32_t R = (uint32_t)G * (uint32_t)G;
     hipError_t e = hipMemsetAsync(c->counters, 0, PM_PIECE_COUNTERS * sizeof(uint32_t), c->stream);     // heavy rows; the piece counts stay
     if (e != hipSuccess) return e;
-    k_heavy_pieces<TP><<<PIECE_SHARDS * 32, BLOCK, 0, c->stream>>>(P, c->key_out, c->piece_list, c->counters + PM_PIECE_COUNTERS,
-                                                                 pm_piece_shard_cap(c->cap), c->pre, c->skip, c->n, c->cap, c->g);
+    k_heavy_pieces<<<PIECE_SHARDS * 32, BLOCK, 0, c->stream>>>(c->frac, c->key_out, c->piece_list, c->counters + PM_PIECE_COUNTERS,
+                                                             pm_piece_shard_cap(c->cap), c->pre, c->skip, c->n, c->cap);
     const size_t tw_bytes = SPECTRUM ? 512 * sizeof(float2) : 0;
     const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double) + tw_bytes;
-    k_deposit_rows<TP, SPECTRUM><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
-        P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
+    k_deposit_rows<SPECTRUM><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
+        c->frac, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
     const int nw = heavy_waves(G);
     const size_t lds_heavy = (size_t)nw * G * sizeof(double);
     // heavy rows always leave as float32 rows of the density mesh; in spectrum mode a small kernel transforms them
     static bool attr_set = false;
     if (!attr_set) {
-        e = hipFuncSetAttribute((const void *)k_deposit_heavy<TP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute((const void *)k_deposit_heavy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_deposit_heavy<TP, false><<<512, nw * 64, lds_heavy, c->stream>>>(P, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density,
-                                                                       c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
+    k_deposit_heavy<false><<<512, nw * 64, lds_heavy, c->stream>>>(c->frac, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density,
+                                                                   c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
     if (SPECTRUM)
         k_heavy_rows_r2c<<<ROW_SHARDS * 16, BLOCK, 0, c->stream>>>(c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, G, c->g.Ghp);
     return hipGetLastError();
@@ -794,13 +804,7 @@ static hipError_t deposit_dispatch(pm_ctx *c, const pm_prec<TP> *P)
 // to_spectrum: leave the z-transformed rows in the half spectrum instead of the density mesh (G = 512 only)
 hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum)
 {
-    int u = c->cur;
-    if (to_spectrum) {
-        if (c->pos_f64) return deposit_dispatch<double, true>(c, c->pd[u]);
-        return deposit_dispatch<float, true>(c, c->pf[u]);
-    }
-    if (c->pos_f64) return deposit_dispatch<double, false>(c, c->pd[u]);
-    return deposit_dispatch<float, false>(c, c->pf[u]);
+    return to_spectrum ? deposit_dispatch<true>(c) : deposit_dispatch<false>(c);
 }
 
 template <typename TP, typename TV>
