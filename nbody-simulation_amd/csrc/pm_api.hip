@@ -121,7 +121,7 @@ void pm_destroy(pm_ctx *c)
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
-    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->piece_list); hipFree(c->skip); hipFree(c->pre);
+    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->piece_list); hipFree(c->skip); hipFree(c->row_flag); hipFree(c->pre);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage); hipFree(c->diag); hipFree(c->density64);
@@ -155,6 +155,7 @@ static int create_impl(pm_ctx *c)
     TRY(dalloc(c, &c->counters, PM_NUM_COUNTERS));
     TRY(dalloc(c, &c->piece_list, pm_piece_list_entries(c->cap)));
     TRY(dalloc(c, &c->skip, cap));
+    TRY(dalloc(c, &c->row_flag, (size_t)G * G));
     TRY(dalloc(c, &c->pre, 8 * cap));
     TRY(dalloc(c, &c->density, M));
     TRY(dalloc(c, &c->potential, M));

@@ -69,6 +69,7 @@ struct pm_ctx {
     uint32_t *counters = nullptr;       // sharded list counters: heavy rows, then heavy-cell pieces (PM_NUM_COUNTERS words)
     uint32_t *piece_list = nullptr;     // first particle of every piece of a heavy cell's run
     uint32_t *skip = nullptr;           // per particle: 0, or one past its piece of a heavy cell (+ head bit)
+    uint8_t *row_flag = nullptr;        // per mesh row: holds a heavy cell
     double *pre = nullptr;              // [8][cap]: corner sums of a piece, at the piece's first particle
 
     // meshes

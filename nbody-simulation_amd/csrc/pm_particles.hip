@@ -154,10 +154,10 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 // them anyway, reads record src[r] and writes it to slot r (k_move_v does it when no gather follows).
 //
 // The same pass prepares the deposit's handling of "heavy" cells (more than HEAVY_CELL
-// particles): it clears skip[] and cuts the runs of heavy cells into pieces for k_heavy_pieces.
-// A piece starts at the first particle of a heavy cell, and at every multiple of HEAVY_PIECE that
-// has at least HEAVY_CELL particles of the same cell on either side (key[] is the sorted key
-// array, so slot r reads its neighbours' keys).
+// particles): it clears skip[], flags the mesh rows that hold a heavy cell and cuts the runs of heavy
+// cells into pieces for k_heavy_pieces.  A piece starts at the first particle of a heavy cell, and at
+// every multiple of HEAVY_PIECE that has at least HEAVY_CELL particles of the same cell on either
+// side (key[] is the sorted key array, so slot r reads its neighbours' keys).
 #ifndef PM_HEAVY_CELL
 #define PM_HEAVY_CELL 128
 #endif
@@ -167,12 +167,17 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 #ifndef PM_HEAVY_RUN
 #define PM_HEAVY_RUN 1024
 #endif
+#ifndef PM_HEAVY_GRID
+#define PM_HEAVY_GRID 2048
+#endif
 constexpr uint32_t HEAVY_CELL = PM_HEAVY_CELL, HEAVY_PIECE = 2048;
 // Lists filled through atomic counters are split into shards, each with its own counter on its own
 // 128-byte line and its own region of the list, so that appends do not queue on one address.
 constexpr uint32_t PIECE_SHARDS = 64, ROW_SHARDS = 16, COUNTER_STRIDE = 32;
 // pieces a block of BLOCK consecutive particles can start: one per HEAVY_CELL + 1 particles, plus a cut
 constexpr uint32_t PIECES_PER_BLOCK = BLOCK / (HEAVY_CELL + 1) + 2;
+// skip[r]: 0 for a particle that adds its own two corner masses; for a particle of a piece, the index
+// one past the piece, with SKIP_HEAD set on the piece's first particle (which adds the piece's sums)
 constexpr uint32_t SKIP_HEAD = 0x80000000u;
 
 // Is index c (a multiple of HEAVY_PIECE, inside a run of key k) the start of a new piece?
@@ -191,8 +196,8 @@ __global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__res
 template <typename TP>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
                           pm_frac *__restrict__ F, const uint32_t *__restrict__ src, const uint32_t *__restrict__ key,
-                          uint32_t *__restrict__ skip, uint32_t *__restrict__ piece_list, uint32_t *__restrict__ piece_count,
-                          uint32_t shard_cap, int64_t n, pm_geom g)
+                          uint32_t *__restrict__ skip, uint8_t *__restrict__ row_flag, uint32_t *__restrict__ piece_list,
+                          uint32_t *__restrict__ piece_count, uint32_t shard_cap, int64_t n, pm_geom g)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     bool piece = false;
@@ -207,6 +212,7 @@ __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__re
         bool head = (r == 0) || key[r - 1] != kcur;
         if (head) {
             piece = (r + HEAVY_CELL < n) && key[r + HEAVY_CELL] == kcur;      // run longer than HEAVY_CELL
+            if (piece) row_flag[kcur / (uint32_t)g.G] = 1;
         } else if (r % HEAVY_PIECE == 0) {
             piece = piece_cut(key, r, kcur, n);
         }
@@ -245,20 +251,20 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 // the four mesh rows (i-di, j-dj), di,dj in {0,1}, through the corners (di,dj,0) into cell k and
 // (di,dj,1) into cell k+1 of their clouds (functions.py:56-68).  With the particles in cell
 // order each of those rows is one contiguous run of the particle array, found through
-// row_start.  A wave walks the four runs, 64 particles at a time, and adds the float64 corner
-// masses into a float64 copy of the row held in LDS; the row is rounded to float32 once, when
-// it is written out.  No global atomics, no mesh-sized index: the only mesh traffic is the one
-// coalesced write of the density.
+// row_start.  A wave walks the four runs as one sequence, 64 particles at a time, and adds the
+// float64 corner masses into a float64 copy of the row held in LDS; the row is rounded to float32
+// once, when it is written out.  No global atomics, no mesh-sized index: the only mesh traffic is
+// the one coalesced write of the density.
 //
 // All adds to an LDS row come from one wave, in program order, and the LDS rows are added in a
 // fixed order, so the sum has one fixed order.
 // Two things keep dense clumps from serialising the walk:
 //  * the runs of heavy cells (more than HEAVY_CELL particles) are summed once, for all eight
-//    corners, by k_heavy_pieces (one wave per piece, fixed butterfly); the walk takes a piece's
-//    sums from pre[] at the piece's first particle and jumps over the rest of the piece;
-//  * rows with a source run of more than HEAVY_RUN particles are left to k_deposit_heavy, where
-//    several waves walk contiguous slices of each run into their own LDS rows and the rows are
-//    added in wave order.
+//    corners, by k_heavy_pieces (one wave per piece, fixed butterfly); a walk takes a piece's sums
+//    from pre[] at the piece's first particle and does nothing for its other particles;
+//  * rows with a source run of more than HEAVY_RUN particles, or with a heavy cell in a source row,
+//    are left to k_deposit_heavy, where several waves walk contiguous slices of each run into their
+//    own LDS rows and the rows are added in wave order.
 constexpr uint32_t HEAVY_RUN = PM_HEAVY_RUN;
 
 // The eight corner masses of a fraction record, mass * wx * wy * wz left to right (functions.py:61-68),
@@ -274,7 +280,8 @@ __device__ __forceinline__ void corner_masses(const pm_frac &f, double w[8])
 
 // One wave per listed piece: the part of the run of its first particle's cell up to the next
 // piece start.  Its eight corner sums go to pre[q*cap + first]; skip[] gets, for every particle of
-// the piece, the index one past the piece (the first one also SKIP_HEAD).
+// the piece, the index one past the piece (the first one also SKIP_HEAD).  Each lane sums every 64th
+// particle, four loads in flight.
 __global__ void __launch_bounds__(BLOCK)
 k_heavy_pieces(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ piece_list,
                const uint32_t *__restrict__ piece_count, uint32_t shard_cap, double *__restrict__ pre,
@@ -294,13 +301,30 @@ k_heavy_pieces(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, 
             if (key[c] != k0 || piece_cut(key, c, k0, n)) { bound = c; break; }
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         uint32_t mine = 0;
-        for (int64_t r = (int64_t)first + lane_id(); r < bound; r += 64) {
-            if (key[r] != k0) break;                      // cell order: the run has ended
-            double w[8];
-            corner_masses(F[r], w);
+        bool more = true;
+        for (int64_t r0 = (int64_t)first + lane_id(); more; r0 += 256) {       // wave-uniform exit
+            uint32_t kk[4];
+            pm_frac ff[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += w[q];
-            ++mine;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t r = r0 + 64 * u;
+                kk[u] = ~k0; ff[u] = pm_frac{0.f, 0.f, 0.f, 0.f};
+                if (r < bound) { kk[u] = key[r]; ff[u] = F[r]; }
+            }
+            bool all = true;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (kk[u] == k0) {                           // cell order: the first mismatch ends the run
+                    double w[8];
+                    corner_masses(ff[u], w);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] += w[q];
+                    ++mine;
+                } else {
+                    all = false;
+                }
+            }
+            more = __all(all);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
@@ -325,92 +349,188 @@ __device__ __forceinline__ void lds_add(double *p, double v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// What one lane holds of a 64-particle pass over a run.
-struct pass_t { uint32_t sk, key; pm_frac f; };
-
-__device__ __forceinline__ pass_t load_pass(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
-                                            const uint32_t *__restrict__ skip, uint32_t base, uint32_t end)
-{
-    pass_t t{};
-    const uint32_t r = base + lane_id();
-    if (r < end) { t.sk = skip[r]; t.key = key[r]; t.f = F[r]; }
-    return t;
-}
-
-// One run of a source row into the LDS row `acc`, 64 particles per pass.  The particles are in
-// cell order, so the lanes of a pass hold non-decreasing k and the lanes that share a cell are
-// neighbours.  Where many lanes share cells their masses are first summed by a segmented scan
-// over the wave (fixed tree order) and only the last lane of every cell adds to LDS; otherwise
-// every lane adds its own.  A piece of a heavy cell is represented by its first particle alone,
-// which adds the sums k_heavy_pieces left in pre[]; when a pass ends inside a piece the walk
-// continues after it.  `cur` is the first pass, already loaded; the next pass is requested
-// before the current one is processed.
-__device__ __forceinline__ void deposit_run(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
-                                            const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
-                                            uint32_t beg, uint32_t end, pass_t cur, int di, int dj, int G, double *acc)
+// The lanes of a pass hold (k, lo, hi): cell and the masses for cells k and k+1 (idle lanes: a k no
+// cell has, distinct per lane).  Lanes that share a cell are mostly neighbours (cell order).  Where
+// many neighbours share cells, each stretch of equal k is first summed by a segmented scan over the
+// wave (fixed tree order) and only its last lane adds to LDS; otherwise every lane adds its own.
+__device__ __forceinline__ void add_pass(double *acc, int G, int k, double lo, double hi, bool add)
 {
     const int lane = lane_id();
-    const double *pre_lo = pre + (int64_t)(di + 2 * dj) * cap, *pre_hi = pre + (int64_t)(di + 2 * dj + 4) * cap;
-    uint32_t base = beg;
-    while (base < end) {                                        // wave-uniform
-        const uint32_t r = base + lane;
-        const bool live = r < end;
-        const uint32_t sk = cur.sk;
-        const pm_frac f = cur.f;
-        const int kc = (int)(cur.key % (uint32_t)G);
-        const uint32_t sk_last = __shfl(sk, 63) & ~SKIP_HEAD;   // 0 unless the pass ends inside a piece
-        const uint32_t next = (sk_last != 0u) ? sk_last : base + 64;
-        if (next < end) cur = load_pass(F, key, skip, next, end);   // in flight while this pass is summed
-        int k = 0x7fffffff - lane;                              // idle lanes: distinct, never equal to a cell
-        double lo = 0.0, hi = 0.0;
-        bool add = false;
-        if (live && sk == 0u) {
-            const double dx = (double)f.dx, dy = (double)f.dy, dz = (double)f.dz;
-            const double w = (double)f.m * (di ? dx : 1.0 - dx) * (dj ? dy : 1.0 - dy);
-            k = kc; lo = w * (1.0 - dz); hi = w * dz;
-            add = true;
-        } else if (sk & SKIP_HEAD) {
-            k = kc;
-            lo = pre_lo[r]; hi = pre_hi[r];
-            add = true;
-        }
-        int kprev = __shfl_up(k, 1);
-        unsigned long long dup = __ballot(lane > 0 && kprev == k);
-        if (__popcll(dup) > 8) {
+    int kprev = __shfl_up(k, 1);
+    const unsigned long long dup = __ballot(lane > 0 && kprev == k);
+    if (__popcll(dup) > 8) {
+        const unsigned long long starts = ~dup;                 // lanes that begin a stretch (bit 0 is set)
+        const int start = 63 - __clzll((long long)(starts & ((2ull << lane) - 1ull)));
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int ku = __shfl_up(k, d);
-                double lu = __shfl_up(lo, d), hu = __shfl_up(hi, d);
-                if (lane >= d && ku == k) { lo += lu; hi += hu; }
-            }
-            int knext = __shfl_down(k, 1);
-            add = add && (lane == 63 || knext != k);             // last lane of its cell: holds the cell's sum
+        for (int d = 1; d < 64; d <<= 1) {
+            double lu = __shfl_up(lo, d), hu = __shfl_up(hi, d);
+            if (lane - d >= start) { lo += lu; hi += hu; }
         }
-        if (add) {
-            lds_add(&acc[k], lo);
-            lds_add(&acc[(k + 1 == G) ? 0 : k + 1], hi);
-        }
-        base = next;
+        add = add && (lane == 63 || ((starts >> (lane + 1)) & 1ull));   // last lane of its stretch: holds the sum
+    }
+    if (add) {
+        lds_add(&acc[k], lo);
+        lds_add(&acc[(k + 1 == G) ? 0 : k + 1], hi);
     }
 }
 
-struct row_runs { uint32_t beg[4], end[4], longest; };
+struct row_runs { uint32_t beg[4], end[4], longest; bool flagged; };
 
 // The four source rows of density row `row`, in the order (di,dj) = (0,0) (1,0) (0,1) (1,1).
-__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uint32_t row, int G)
+__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, const uint8_t *__restrict__ row_flag, uint32_t row, int G)
 {
     int i = (int)(row / (uint32_t)G), j = (int)(row % (uint32_t)G);
     int im = (i == 0) ? G - 1 : i - 1, jm = (j == 0) ? G - 1 : j - 1;
     uint32_t src[4] = {(uint32_t)(i * G + j), (uint32_t)(im * G + j), (uint32_t)(i * G + jm), (uint32_t)(im * G + jm)};
     row_runs t;
     t.longest = 0;
+    uint32_t fl = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         t.beg[q] = rs[src[q]]; t.end[q] = rs[src[q] + 1];
+        fl |= row_flag[src[q]];
         uint32_t len = t.end[q] - t.beg[q];
         t.longest = len > t.longest ? len : t.longest;
     }
+    t.flagged = fl != 0;
     return t;
+}
+
+// What one lane holds of a 64-particle pass of a light row's walk.
+struct light_t { uint32_t key; pm_frac f; };
+
+// The four runs of a light row (no heavy cell) walked as one sequence of `total` particles: entry v
+// is particle slot(v) of run q(v).
+struct packed_runs {
+    uint32_t o1, o2, o3, total, b0, b1, b2, b3;
+    __device__ __forceinline__ explicit packed_runs(const row_runs &t)
+    {
+        o1 = t.end[0] - t.beg[0]; o2 = o1 + (t.end[1] - t.beg[1]); o3 = o2 + (t.end[2] - t.beg[2]);
+        total = o3 + (t.end[3] - t.beg[3]);
+        b0 = t.beg[0]; b1 = t.beg[1] - o1; b2 = t.beg[2] - o2; b3 = t.beg[3] - o3;     // modulo 2^32
+    }
+    __device__ __forceinline__ int run(uint32_t v) const { return (int)(v >= o1) + (int)(v >= o2) + (int)(v >= o3); }
+    __device__ __forceinline__ uint32_t slot(uint32_t v, int q) const { return v + (q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3); }
+    __device__ __forceinline__ light_t load(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, uint32_t base) const
+    {
+        light_t t{};
+        const uint32_t v = base + lane_id();
+        if (v < total) { const uint32_t r = slot(v, run(v)); t.key = key[r]; t.f = F[r]; }
+        return t;
+    }
+};
+
+__device__ __forceinline__ void deposit_light(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const packed_runs &p,
+                                              light_t cur, int G, double *acc)
+{
+    const int lane = lane_id();
+    for (uint32_t base = 0; base < p.total; base += 64) {       // wave-uniform
+        const uint32_t v = base + lane;
+        const pm_frac f = cur.f;
+        const int kc = (int)(cur.key % (uint32_t)G);
+        if (base + 64 < p.total) cur = p.load(F, key, base + 64);   // in flight while this pass is summed
+        int k = 0x7fffffff - lane;
+        double lo = 0.0, hi = 0.0;
+        const bool live = v < p.total;
+        if (live) {
+            const int q = p.run(v);
+            const double dx = (double)f.dx, dy = (double)f.dy, dz = (double)f.dz;
+            const double w = (double)f.m * ((q & 1) ? dx : 1.0 - dx) * ((q & 2) ? dy : 1.0 - dy);
+            k = kc; lo = w * (1.0 - dz); hi = w * dz;
+        }
+        add_pass(acc, G, k, lo, hi, live);
+    }
+}
+
+// What one lane holds of a 64-particle pass over a run of a heavy row.
+struct heavy_t { uint32_t sk, key; pm_frac f; };
+
+__device__ __forceinline__ heavy_t load_heavy(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
+                                              const uint32_t *__restrict__ skip, uint32_t base, uint32_t end)
+{
+    heavy_t t{};
+    t.sk = 1u;                                          // past the end: neither adds nor heads a piece
+    const uint32_t r = base + lane_id();
+    if (r < end) { t.sk = skip[r]; t.key = key[r]; t.f = F[r]; }
+    return t;
+}
+
+constexpr int HEAD_LIST = 128;      // entries of a wave's list of piece heads (flushed at 64; a pass adds at most 64)
+
+// Adds the sums of the listed pieces: entry = (first particle, cell k).
+__device__ __forceinline__ void flush_heads(const uint2 *list, uint32_t cnt, const double *__restrict__ pre_lo,
+                                            const double *__restrict__ pre_hi, int G, double *acc)
+{
+    pmfft::wave_sync();
+    for (uint32_t e = lane_id(); e < cnt; e += 64) {
+        const uint2 h = list[e];
+        const double lo = pre_lo[h.x], hi = pre_hi[h.x];
+        lds_add(&acc[h.y], lo);
+        lds_add(&acc[(h.y + 1 == (uint32_t)G) ? 0 : h.y + 1], hi);
+    }
+    pmfft::wave_sync();
+}
+
+// Particles [beg, end) of one source row into the LDS row `acc`, 64 per pass, three passes ahead in
+// flight (the inner loop is unrolled by four so that a pass stays in the registers it was loaded
+// into).  Light particles add their own masses; the first particle of a piece is put on the wave's
+// list `heads`, and the listed pieces' sums are fetched and added 64 at a time; the other particles of
+// a piece do nothing.  When a pass ends inside a piece that reaches beyond the passes in flight, the
+// walk restarts at the end of the piece.
+__device__ __forceinline__ void deposit_heavy_run(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
+                                                  const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
+                                                  uint32_t beg, uint32_t end, int di, int dj, int G, double *acc, uint2 *heads)
+{
+    const int lane = lane_id();
+    const double *pre_lo = pre + (int64_t)(di + 2 * dj) * cap, *pre_hi = pre + (int64_t)(di + 2 * dj + 4) * cap;
+    uint32_t cnt = 0;
+    // returns where to go on: the next pass, or past a long piece
+    auto pass = [&](const heavy_t &a, uint32_t base) -> uint32_t {
+        const int kc = (int)(a.key % (uint32_t)G);
+        int k = 0x7fffffff - lane;
+        double lo = 0.0, hi = 0.0;
+        const bool light = a.sk == 0u;
+        if (light) {
+            const double dx = (double)a.f.dx, dy = (double)a.f.dy, dz = (double)a.f.dz;
+            const double w = (double)a.f.m * (di ? dx : 1.0 - dx) * (dj ? dy : 1.0 - dy);
+            k = kc; lo = w * (1.0 - dz); hi = w * dz;
+        }
+        add_pass(acc, G, k, lo, hi, light);
+        const bool head = (a.sk & SKIP_HEAD) != 0u;
+        const unsigned long long hm = __ballot(head);
+        if (hm) {
+            if (head) heads[cnt + __popcll(hm & ((1ull << lane) - 1ull))] = make_uint2(base + lane, (uint32_t)kc);
+            cnt += (uint32_t)__popcll(hm);
+            if (cnt >= 64) { flush_heads(heads, cnt, pre_lo, pre_hi, G, acc); cnt = 0; }
+        }
+        const uint32_t past = __shfl(a.sk, 63) & ~SKIP_HEAD;       // > 1 when the pass ends inside a piece
+        return (past >= base + 256 && past > 1u) ? past : base + 64;
+    };
+    uint32_t base = beg;
+    while (base < end) {                                        // wave-uniform throughout
+        heavy_t p0 = load_heavy(F, key, skip, base, end), p1 = load_heavy(F, key, skip, base + 64, end),
+                p2 = load_heavy(F, key, skip, base + 128, end), p3;
+        for (;;) {
+            uint32_t next;
+            p3 = load_heavy(F, key, skip, base + 192, end);
+            next = pass(p0, base);
+            if (next != base + 64 || next >= end) { base = next; break; }
+            base = next;
+            p0 = load_heavy(F, key, skip, base + 192, end);
+            next = pass(p1, base);
+            if (next != base + 64 || next >= end) { base = next; break; }
+            base = next;
+            p1 = load_heavy(F, key, skip, base + 192, end);
+            next = pass(p2, base);
+            if (next != base + 64 || next >= end) { base = next; break; }
+            base = next;
+            p2 = load_heavy(F, key, skip, base + 192, end);
+            next = pass(p3, base);
+            if (next != base + 64 || next >= end) { base = next; break; }
+            base = next;
+        }
+    }
+    if (cnt) flush_heads(heads, cnt, pre_lo, pre_hi, G, acc);
 }
 
 // A summed row leaves the kernel either as G float32 densities (SPECTRUM = false) or, for G = 512,
@@ -451,12 +571,11 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
     }
 }
 
-// One wave per density row: the first pass of each of the four runs is requested before any is
-// processed, then the runs are walked in the order q = 0..3.
+// One wave per density row; rows for k_deposit_heavy are only listed.
 template <bool SPECTRUM>
 __global__ void __launch_bounds__(BLOCK)
-k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
-               const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
+k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint8_t *__restrict__ row_flag,
+               const uint32_t *__restrict__ rs, float *__restrict__ density,
                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
                uint32_t *__restrict__ heavy_rows, uint32_t *__restrict__ heavy_count, pm_geom g)
 {
@@ -471,8 +590,8 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, 
     }
     if (row >= R) return;
     double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
-    row_runs t = runs_of(rs, row, G);
-    if (t.longest > HEAVY_RUN) {
+    const row_runs t = runs_of(rs, row_flag, row, G);
+    if (t.longest > HEAVY_RUN || t.flagged) {
         if (lane_id() == 0) {
             const uint32_t shard = row % ROW_SHARDS;        // holds at most R / ROW_SHARDS + 1 rows
             heavy_rows[(size_t)shard * (R / ROW_SHARDS + 1) + atomicAdd(heavy_count + shard * COUNTER_STRIDE, 1u)] = row;
@@ -483,31 +602,30 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, 
         emit_empty_row<SPECTRUM>(density, spectrum, row, G, g.Ghp);
         return;
     }
-    pass_t first[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) first[q] = load_pass(F, key, skip, t.beg[q], t.end[q]);
+    const packed_runs p(t);
+    const light_t first = p.load(F, key, 0);
     for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) deposit_run(F, key, skip, pre, cap, t.beg[q], t.end[q], first[q], q & 1, q >> 1, G, acc);
+    deposit_light(F, key, p, first, G, acc);
     pmfft::wave_sync();
     emit_row<SPECTRUM>(acc, tw, density, spectrum, row, G, g.Ghp);
 }
 
-// Rows with a long run: a block of 4*S waves; wave w walks slice w/4 of run w%4 into its own LDS
-// row, and the rows are added in wave order.
+// Listed rows: a block of 4*S waves; wave w walks slice w/4 of run w%4 into its own LDS row, and the
+// rows are added in wave order.
 template <bool SPECTRUM>
 __global__ void __launch_bounds__(1024)
 k_deposit_heavy(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
-                const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs, float *__restrict__ density,
-                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
+                const uint8_t *__restrict__ row_flag, const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs,
+                float *__restrict__ density, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
                 const uint32_t *__restrict__ heavy_rows, const uint32_t *__restrict__ heavy_count, pm_geom g)
 {
-    extern __shared__ double lds_rows[];                // one row of G doubles per wave, then 512 twiddles if SPECTRUM
+    extern __shared__ double lds_rows[];    // per wave a row of G doubles, then per wave a head list, then 512 twiddles if SPECTRUM
     const int G = g.G;
     const int nw = blockDim.x >> 6, w = threadIdx.x >> 6;
     const int q = w & 3, slice = w >> 2, slices = nw >> 2;
     double *acc = lds_rows + (size_t)w * G;
-    float2 *tw = (float2 *)(lds_rows + (size_t)nw * G);
+    uint2 *heads = (uint2 *)(lds_rows + (size_t)nw * G) + (size_t)w * HEAD_LIST;
+    float2 *tw = (float2 *)((uint2 *)(lds_rows + (size_t)nw * G) + (size_t)nw * HEAD_LIST);
     if constexpr (SPECTRUM)
         for (int c = threadIdx.x; c < 512; c += blockDim.x) tw[c] = twiddle[c];
     // blocks s, s + ROW_SHARDS, ... serve shard s
@@ -516,7 +634,7 @@ k_deposit_heavy(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     heavy_rows += (size_t)shard * ((uint32_t)G * (uint32_t)G / ROW_SHARDS + 1);
     for (uint32_t e = blockIdx.x / ROW_SHARDS; e < cnt; e += gridDim.x / ROW_SHARDS) {
         const uint32_t row = heavy_rows[e];
-        row_runs t = runs_of(rs, row, G);
+        const row_runs t = runs_of(rs, row_flag, row, G);
         for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
         // slices are whole multiples of 64 particles
         uint32_t len = t.end[q] - t.beg[q];
@@ -524,7 +642,7 @@ k_deposit_heavy(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         uint32_t b = t.beg[q] + (uint32_t)slice * sl, e2 = b + sl;
         if (b > t.end[q]) b = t.end[q];
         if (e2 > t.end[q]) e2 = t.end[q];
-        deposit_run(F, key, skip, pre, cap, b, e2, load_pass(F, key, skip, b, e2), q & 1, q >> 1, G, acc);
+        deposit_heavy_run(F, key, skip, pre, cap, b, e2, q & 1, q >> 1, G, acc, heads);
         __syncthreads();
         // column c of the block's rows, added in wave order, lands in row 0
         for (int c = threadIdx.x; c < G; c += blockDim.x) {
@@ -738,11 +856,13 @@ hipError_t pm_launch_reorder(pm_ctx *c)
     int64_t n = c->n;
     hipError_t e = hipMemsetAsync(c->counters, 0, PM_NUM_COUNTERS * sizeof(uint32_t), c->stream);     // heavy rows, heavy-cell pieces
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(c->row_flag, 0, (size_t)c->g.G * c->g.G, c->stream);
+    if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     int u = c->cur, w = 1 - u;
     const uint32_t cap = pm_piece_shard_cap(c->cap);
-    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
-    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, c->key_out, c->skip, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
+    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, c->key_out, c->skip, c->row_flag, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
+    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, c->key_out, c->skip, c->row_flag, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
     c->cur = w;
     c->v_stale = true;
     return hipGetLastError();
@@ -768,7 +888,7 @@ size_t pm_heavy_row_entries(int G) { return ((size_t)G * G / ROW_SHARDS + 1) * R
 
 static int heavy_waves(int G)
 {
-    int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double))) & ~3;     // a multiple of 4: waves per run
+    int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double) + HEAD_LIST * sizeof(uint2))) & ~3;     // a multiple of 4: waves per run
     return nw > PM_HEAVY_WAVES ? PM_HEAVY_WAVES : (nw < 4 ? 4 : nw);
 }
 
@@ -784,9 +904,9 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     const size_t tw_bytes = SPECTRUM ? 512 * sizeof(float2) : 0;
     const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double) + tw_bytes;
     k_deposit_rows<SPECTRUM><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
-        c->frac, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
+        c->frac, c->key_out, c->row_flag, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
     const int nw = heavy_waves(G);
-    const size_t lds_heavy = (size_t)nw * G * sizeof(double);
+    const size_t lds_heavy = (size_t)nw * (G * sizeof(double) + HEAD_LIST * sizeof(uint2));
     // heavy rows always leave as float32 rows of the density mesh; in spectrum mode a small kernel transforms them
     static bool attr_set = false;
     if (!attr_set) {
@@ -794,7 +914,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_deposit_heavy<false><<<512, nw * 64, lds_heavy, c->stream>>>(c->frac, c->key_out, c->skip, c->pre, c->cap, c->row_start, c->density,
+    k_deposit_heavy<false><<<PM_HEAVY_GRID, nw * 64, lds_heavy, c->stream>>>(c->frac, c->key_out, c->skip, c->row_flag, c->pre, c->cap, c->row_start, c->density,
                                                                    c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
     if (SPECTRUM)
         k_heavy_rows_r2c<<<ROW_SHARDS * 16, BLOCK, 0, c->stream>>>(c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, G, c->g.Ghp);

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpm.so")
+# PM_LIBRARY names another build of the same library (e.g. a tuning variant)
+LIB_PATH = os.environ.get("PM_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libpm.so")
 
 PM_F32, PM_F64 = 0, 1
 MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ = range(5)
