@@ -121,7 +121,7 @@ void pm_destroy(pm_ctx *c)
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
-    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->piece_list); hipFree(c->skip); hipFree(c->row_flag); hipFree(c->pre);
+    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage); hipFree(c->diag); hipFree(c->density64);
@@ -144,19 +144,17 @@ static int create_impl(pm_ctx *c)
     for (int s = 0; s < PM_NSTAGES; ++s)
         for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
 
-    TRY(dalloc(c, &c->frac, cap));
-    TRY(dalloc(c, &c->key_in, cap));
-    TRY(dalloc(c, &c->key_out, cap));
+    // the deposit reads keys and fraction records in groups of four: three entries of slack
+    TRY(dalloc(c, &c->frac, cap + 4));
+    TRY(dalloc(c, &c->key_in, cap + 4));
+    TRY(dalloc(c, &c->key_out, cap + 4));
     TRY(dalloc(c, &c->src, cap));
     c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, (size_t)G * G + 1));
-    TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G)));
-    TRY(dalloc(c, &c->counters, PM_NUM_COUNTERS));
-    TRY(dalloc(c, &c->piece_list, pm_piece_list_entries(c->cap)));
-    TRY(dalloc(c, &c->skip, cap));
-    TRY(dalloc(c, &c->row_flag, (size_t)G * G));
-    TRY(dalloc(c, &c->pre, 8 * cap));
+    TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G, cap)));
+    TRY(dalloc(c, &c->counters, 1));
+    TRY(dalloc(c, &c->unit_rows, pm_unit_rows(G, cap) * (size_t)G));
     TRY(dalloc(c, &c->density, M));
     TRY(dalloc(c, &c->potential, M));
     for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));

@@ -65,12 +65,9 @@ struct pm_ctx {
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
-    uint32_t *heavy_rows = nullptr;     // density rows fed by more particles than one wave should walk
-    uint32_t *counters = nullptr;       // sharded list counters: heavy rows, then heavy-cell pieces (PM_NUM_COUNTERS words)
-    uint32_t *piece_list = nullptr;     // first particle of every piece of a heavy cell's run
-    uint32_t *skip = nullptr;           // per particle: 0, or one past its piece of a heavy cell (+ head bit)
-    uint8_t *row_flag = nullptr;        // per mesh row: holds a heavy cell
-    double *pre = nullptr;              // [8][cap]: corner sums of a piece, at the piece's first particle
+    uint2 *heavy_rows = nullptr;        // density rows fed by more particles than one wave should walk: (row, first unit)
+    unsigned long long *counters = nullptr;     // entries of heavy_rows (high word) and units handed out (low word)
+    double *unit_rows = nullptr;        // one row of G doubles per unit of a listed row
 
     // meshes
     float *density = nullptr, *potential = nullptr, *grad[3] = {};
@@ -95,11 +92,8 @@ struct pm_ctx {
     std::string err;
 };
 
-// counters[]: 16 heavy-row shards then 64 piece shards, one counter per 32 words (its own 128-byte line)
-constexpr int PM_PIECE_COUNTERS = 16 * 32, PM_NUM_COUNTERS = (16 + 64) * 32;
-uint32_t pm_piece_shard_cap(int64_t cap);
-size_t pm_piece_list_entries(int64_t cap);
-size_t pm_heavy_row_entries(int G);
+size_t pm_heavy_row_entries(int G, int64_t cap);
+size_t pm_unit_rows(int G, int64_t cap);
 
 // ---- launchers (each enqueues on ctx->stream and returns a hipError_t) ----------------------
 // stage -> records: positions (n,3) of the given dtype + masses (or ones), velocities (or zeros) + iota ids

@@ -153,38 +153,20 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 // here and not once per visit there.  The velocity records are not moved here: the gather, which reads and writes every one of
 // them anyway, reads record src[r] and writes it to slot r (k_move_v does it when no gather follows).
 //
-// The same pass prepares the deposit's handling of "heavy" cells (more than HEAVY_CELL
-// particles): it clears skip[], flags the mesh rows that hold a heavy cell and cuts the runs of heavy
-// cells into pieces for k_heavy_pieces.  A piece starts at the first particle of a heavy cell, and at
-// every multiple of HEAVY_PIECE that has at least HEAVY_CELL particles of the same cell on either
-// side (key[] is the sorted key array, so slot r reads its neighbours' keys).
-#ifndef PM_HEAVY_CELL
-#define PM_HEAVY_CELL 128
+// Tuning: a density row fed by at most PM_PACKED_MAX particles is walked one particle per lane;
+// one fed by more than PM_LIGHT_MAX is cut into units of PM_UNIT particles.
+#ifndef PM_PACKED_MAX
+#define PM_PACKED_MAX 512
 #endif
-#ifndef PM_HEAVY_WAVES
-#define PM_HEAVY_WAVES 8
+#ifndef PM_LIGHT_MAX
+#define PM_LIGHT_MAX 4096
 #endif
-#ifndef PM_HEAVY_RUN
-#define PM_HEAVY_RUN 1024
+#ifndef PM_UNIT
+#define PM_UNIT 2048
 #endif
-#ifndef PM_HEAVY_GRID
-#define PM_HEAVY_GRID 2048
+#ifndef PM_UNIT_GRID
+#define PM_UNIT_GRID 2048
 #endif
-constexpr uint32_t HEAVY_CELL = PM_HEAVY_CELL, HEAVY_PIECE = 2048;
-// Lists filled through atomic counters are split into shards, each with its own counter on its own
-// 128-byte line and its own region of the list, so that appends do not queue on one address.
-constexpr uint32_t PIECE_SHARDS = 64, ROW_SHARDS = 16, COUNTER_STRIDE = 32;
-// pieces a block of BLOCK consecutive particles can start: one per HEAVY_CELL + 1 particles, plus a cut
-constexpr uint32_t PIECES_PER_BLOCK = BLOCK / (HEAVY_CELL + 1) + 2;
-// skip[r]: 0 for a particle that adds its own two corner masses; for a particle of a piece, the index
-// one past the piece, with SKIP_HEAD set on the piece's first particle (which adds the piece's sums)
-constexpr uint32_t SKIP_HEAD = 0x80000000u;
-
-// Is index c (a multiple of HEAVY_PIECE, inside a run of key k) the start of a new piece?
-__device__ __forceinline__ bool piece_cut(const uint32_t *__restrict__ key, int64_t c, uint32_t k, int64_t n)
-{
-    return c >= HEAVY_CELL && c + HEAVY_CELL - 1 < n && key[c - HEAVY_CELL] == k && key[c + HEAVY_CELL - 1] == k;
-}
 
 template <typename TV>
 __global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__restrict__ Vout, const uint32_t *__restrict__ src, int64_t n)
@@ -195,39 +177,14 @@ __global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__res
 
 template <typename TP>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
-                          pm_frac *__restrict__ F, const uint32_t *__restrict__ src, const uint32_t *__restrict__ key,
-                          uint32_t *__restrict__ skip, uint8_t *__restrict__ row_flag, uint32_t *__restrict__ piece_list,
-                          uint32_t *__restrict__ piece_count, uint32_t shard_cap, int64_t n, pm_geom g)
+                          pm_frac *__restrict__ F, const uint32_t *__restrict__ src, int64_t n, pm_geom g)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    bool piece = false;
-    if (r < n) {
-        int64_t s = src[r];
-        const pm_prec<TP> rec = Pin[s];
-        Pout[r] = rec;
-        const cell_t c = locate(rec, g);
-        F[r] = pm_frac{(float)c.dx, (float)c.dy, (float)c.dz, rec.m};
-        skip[r] = 0u;
-        uint32_t kcur = key[r];
-        bool head = (r == 0) || key[r - 1] != kcur;
-        if (head) {
-            piece = (r + HEAVY_CELL < n) && key[r + HEAVY_CELL] == kcur;      // run longer than HEAVY_CELL
-            if (piece) row_flag[kcur / (uint32_t)g.G] = 1;
-        } else if (r % HEAVY_PIECE == 0) {
-            piece = piece_cut(key, r, kcur, n);
-        }
-    }
-    // one atomic per wave, on the counter of this block's shard (a shard holds at most
-    // PIECES_PER_BLOCK entries per block that feeds it: shard_cap)
-    unsigned long long pm = __ballot(piece);
-    if (pm) {
-        const uint32_t shard = blockIdx.x % PIECE_SHARDS;
-        int leader = __ffsll((long long)pm) - 1;
-        uint32_t base = 0;
-        if (lane_id() == leader) base = atomicAdd(piece_count + shard * COUNTER_STRIDE, (uint32_t)__popcll(pm));
-        base = __shfl(base, leader);
-        if (piece) piece_list[(size_t)shard * shard_cap + base + __popcll(pm & ((1ull << lane_id()) - 1ull))] = (uint32_t)r;
-    }
+    if (r >= n) return;
+    const pm_prec<TP> rec = Pin[src[r]];
+    Pout[r] = rec;
+    const cell_t c = locate(rec, g);
+    F[r] = pm_frac{(float)c.dx, (float)c.dy, (float)c.dz, rec.m};
 }
 
 // row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
@@ -251,107 +208,35 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 // the four mesh rows (i-di, j-dj), di,dj in {0,1}, through the corners (di,dj,0) into cell k and
 // (di,dj,1) into cell k+1 of their clouds (functions.py:56-68).  With the particles in cell
 // order each of those rows is one contiguous run of the particle array, found through
-// row_start.  A wave walks the four runs as one sequence, 64 particles at a time, and adds the
-// float64 corner masses into a float64 copy of the row held in LDS; the row is rounded to float32
-// once, when it is written out.  No global atomics, no mesh-sized index: the only mesh traffic is
-// the one coalesced write of the density.
+// row_start.  A wave walks the runs and adds the float64 corner masses (mass * wx * wy * wz left
+// to right, weights in float64 from the float32 offsets of the fraction records) into a float64
+// copy of the row held in LDS; the row is rounded to float32 once, when it is written out.  No
+// global atomics, no mesh-sized index: the only mesh traffic is the one coalesced write of the
+// density.
 //
 // All adds to an LDS row come from one wave, in program order, and the LDS rows are added in a
 // fixed order, so the sum has one fixed order.
-// Two things keep dense clumps from serialising the walk:
-//  * the runs of heavy cells (more than HEAVY_CELL particles) are summed once, for all eight
-//    corners, by k_heavy_pieces (one wave per piece, fixed butterfly); a walk takes a piece's sums
-//    from pre[] at the piece's first particle and does nothing for its other particles;
-//  * rows with a source run of more than HEAVY_RUN particles, or with a heavy cell in a source row,
-//    are left to k_deposit_heavy, where several waves walk contiguous slices of each run into their
-//    own LDS rows and the rows are added in wave order.
-constexpr uint32_t HEAVY_RUN = PM_HEAVY_RUN;
-
-// The eight corner masses of a fraction record, mass * wx * wy * wz left to right (functions.py:61-68),
-// q = di + 2*dj + 4*dk; weights in float64 from the float32 offsets.
-__device__ __forceinline__ void corner_masses(const pm_frac &f, double w[8])
-{
-    const double dx = (double)f.dx, dy = (double)f.dy, dz = (double)f.dz, mm = (double)f.m;
-    const double mx[2] = {mm * (1.0 - dx), mm * dx};
-    const double wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w[q] = mx[q & 1] * wy[(q >> 1) & 1] * wz[q >> 2];
-}
-
-// One wave per listed piece: the part of the run of its first particle's cell up to the next
-// piece start.  Its eight corner sums go to pre[q*cap + first]; skip[] gets, for every particle of
-// the piece, the index one past the piece (the first one also SKIP_HEAD).  Each lane sums every 64th
-// particle, four loads in flight.
-__global__ void __launch_bounds__(BLOCK)
-k_heavy_pieces(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ piece_list,
-               const uint32_t *__restrict__ piece_count, uint32_t shard_cap, double *__restrict__ pre,
-               uint32_t *__restrict__ skip, int64_t n, int64_t cap)
-{
-    // blocks s, s + PIECE_SHARDS, ... serve shard s
-    const uint32_t shard = blockIdx.x % PIECE_SHARDS;
-    const uint32_t cnt = piece_count[shard * COUNTER_STRIDE];
-    const uint32_t waves = (gridDim.x / PIECE_SHARDS) * (BLOCK / 64);
-    piece_list += (size_t)shard * shard_cap;
-    for (uint32_t e = (blockIdx.x / PIECE_SHARDS) * (BLOCK / 64) + (threadIdx.x >> 6); e < cnt; e += waves) {
-        const uint32_t first = piece_list[e];
-        const uint32_t k0 = key[first];
-        // the piece ends where the run ends or at the next cut that starts a piece
-        int64_t bound = n;
-        for (int64_t c = ((int64_t)(first / HEAVY_PIECE) + 1) * HEAVY_PIECE; c < n; c += HEAVY_PIECE)
-            if (key[c] != k0 || piece_cut(key, c, k0, n)) { bound = c; break; }
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t mine = 0;
-        bool more = true;
-        for (int64_t r0 = (int64_t)first + lane_id(); more; r0 += 256) {       // wave-uniform exit
-            uint32_t kk[4];
-            pm_frac ff[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t r = r0 + 64 * u;
-                kk[u] = ~k0; ff[u] = pm_frac{0.f, 0.f, 0.f, 0.f};
-                if (r < bound) { kk[u] = key[r]; ff[u] = F[r]; }
-            }
-            bool all = true;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (kk[u] == k0) {                           // cell order: the first mismatch ends the run
-                    double w[8];
-                    corner_masses(ff[u], w);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] += w[q];
-                    ++mine;
-                } else {
-                    all = false;
-                }
-            }
-            more = __all(all);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-        const uint32_t end = first + mine;
-        for (uint32_t r = first + lane_id(); r < end; r += 64) skip[r] = (r == first) ? (end | SKIP_HEAD) : end;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off);
-        }
-        if (lane_id() < 8) {
-            double v = acc[0];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) v = (lane_id() == q) ? acc[q] : v;
-            pre[(int64_t)lane_id() * cap + first] = v;
-        }
-    }
-}
+//
+// Two walks.  Rows fed by few particles take their four runs as one packed sequence, one particle
+// per lane and pass.  Longer runs are walked 256 particles at a time, each lane taking four
+// consecutive particles: in cell order these mostly share a cell, so the lane sums them in
+// registers and adds to LDS only when the cell changes; what a lane still holds at the end of the
+// four goes through add_pass, which first combines neighbouring lanes that hold the same cell.
+//
+// A row fed by more than LIGHT_MAX particles would keep its wave busy long after the others have
+// finished.  Such rows are listed instead; their particles (the four runs as one sequence) are cut
+// into units of UNIT, k_deposit_units sums each unit into a float64 row of its own in global
+// memory, and k_sum_units adds a row's units in order and emits the row.
+constexpr uint32_t PACKED_MAX = PM_PACKED_MAX, LIGHT_MAX = PM_LIGHT_MAX, UNIT = PM_UNIT;
 
 __device__ __forceinline__ void lds_add(double *p, double v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// The lanes of a pass hold (k, lo, hi): cell and the masses for cells k and k+1 (idle lanes: a k no
-// cell has, distinct per lane).  Lanes that share a cell are mostly neighbours (cell order).  Where
-// many neighbours share cells, each stretch of equal k is first summed by a segmented scan over the
+// The lanes hold (k, lo, hi): cell and the masses for cells k and k+1 (idle lanes: a k no cell
+// has, distinct per lane).  Lanes that share a cell are mostly neighbours (cell order).  Where many
+// neighbours share cells, each stretch of equal k is first summed by a segmented scan over the
 // wave (fixed tree order) and only its last lane adds to LDS; otherwise every lane adds its own.
 __device__ __forceinline__ void add_pass(double *acc, int G, int k, double lo, double hi, bool add)
 {
@@ -374,43 +259,52 @@ __device__ __forceinline__ void add_pass(double *acc, int G, int k, double lo, d
     }
 }
 
-struct row_runs { uint32_t beg[4], end[4], longest; bool flagged; };
+// beg/end: particle range of the four source rows of a density row, in the order
+// (di,dj) = (0,0) (1,0) (0,1) (1,1); key0: the key of cell k = 0 of each source row.
+struct row_runs { uint32_t beg[4], end[4], key0[4], longest; };
 
-// The four source rows of density row `row`, in the order (di,dj) = (0,0) (1,0) (0,1) (1,1).
-__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, const uint8_t *__restrict__ row_flag, uint32_t row, int G)
+__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uint32_t row, int G)
 {
     int i = (int)(row / (uint32_t)G), j = (int)(row % (uint32_t)G);
     int im = (i == 0) ? G - 1 : i - 1, jm = (j == 0) ? G - 1 : j - 1;
     uint32_t src[4] = {(uint32_t)(i * G + j), (uint32_t)(im * G + j), (uint32_t)(i * G + jm), (uint32_t)(im * G + jm)};
     row_runs t;
     t.longest = 0;
-    uint32_t fl = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         t.beg[q] = rs[src[q]]; t.end[q] = rs[src[q] + 1];
-        fl |= row_flag[src[q]];
+        t.key0[q] = src[q] * (uint32_t)G;
         uint32_t len = t.end[q] - t.beg[q];
         t.longest = len > t.longest ? len : t.longest;
     }
-    t.flagged = fl != 0;
     return t;
 }
 
-// What one lane holds of a 64-particle pass of a light row's walk.
+// The masses a particle adds to cells k and k+1 of the density row that lies (di,dj) from its own.
+__device__ __forceinline__ void corner_pair(const pm_frac &f, bool di, bool dj, double &lo, double &hi)
+{
+    const double dx = (double)f.dx, dy = (double)f.dy, dz = (double)f.dz;
+    const double w = (double)f.m * (di ? dx : 1.0 - dx) * (dj ? dy : 1.0 - dy);
+    lo = w * (1.0 - dz); hi = w * dz;
+}
+
+// ---- packed walk: one particle per lane and pass
+
 struct light_t { uint32_t key; pm_frac f; };
 
-// The four runs of a light row (no heavy cell) walked as one sequence of `total` particles: entry v
-// is particle slot(v) of run q(v).
+// The four runs as one sequence of `total` particles: entry v is particle slot(v) of run run(v).
 struct packed_runs {
-    uint32_t o1, o2, o3, total, b0, b1, b2, b3;
+    uint32_t o1, o2, o3, total, b0, b1, b2, b3, k0, k1, k2, k3;
     __device__ __forceinline__ explicit packed_runs(const row_runs &t)
     {
         o1 = t.end[0] - t.beg[0]; o2 = o1 + (t.end[1] - t.beg[1]); o3 = o2 + (t.end[2] - t.beg[2]);
         total = o3 + (t.end[3] - t.beg[3]);
         b0 = t.beg[0]; b1 = t.beg[1] - o1; b2 = t.beg[2] - o2; b3 = t.beg[3] - o3;     // modulo 2^32
+        k0 = t.key0[0]; k1 = t.key0[1]; k2 = t.key0[2]; k3 = t.key0[3];
     }
     __device__ __forceinline__ int run(uint32_t v) const { return (int)(v >= o1) + (int)(v >= o2) + (int)(v >= o3); }
     __device__ __forceinline__ uint32_t slot(uint32_t v, int q) const { return v + (q == 0 ? b0 : q == 1 ? b1 : q == 2 ? b2 : b3); }
+    __device__ __forceinline__ uint32_t key0(int q) const { return q == 0 ? k0 : q == 1 ? k1 : q == 2 ? k2 : k3; }
     __device__ __forceinline__ light_t load(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, uint32_t base) const
     {
         light_t t{};
@@ -420,117 +314,83 @@ struct packed_runs {
     }
 };
 
-__device__ __forceinline__ void deposit_light(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const packed_runs &p,
-                                              light_t cur, int G, double *acc)
+__device__ __forceinline__ void deposit_packed(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const packed_runs &p,
+                                               light_t cur, int G, double *acc)
 {
     const int lane = lane_id();
     for (uint32_t base = 0; base < p.total; base += 64) {       // wave-uniform
         const uint32_t v = base + lane;
         const pm_frac f = cur.f;
-        const int kc = (int)(cur.key % (uint32_t)G);
+        const uint32_t kk = cur.key;
         if (base + 64 < p.total) cur = p.load(F, key, base + 64);   // in flight while this pass is summed
         int k = 0x7fffffff - lane;
         double lo = 0.0, hi = 0.0;
         const bool live = v < p.total;
         if (live) {
             const int q = p.run(v);
-            const double dx = (double)f.dx, dy = (double)f.dy, dz = (double)f.dz;
-            const double w = (double)f.m * ((q & 1) ? dx : 1.0 - dx) * ((q & 2) ? dy : 1.0 - dy);
-            k = kc; lo = w * (1.0 - dz); hi = w * dz;
+            k = (int)(kk - p.key0(q));
+            corner_pair(f, q & 1, q & 2, lo, hi);
         }
         add_pass(acc, G, k, lo, hi, live);
     }
 }
 
-// What one lane holds of a 64-particle pass over a run of a heavy row.
-struct heavy_t { uint32_t sk, key; pm_frac f; };
+// ---- chunked walk: four consecutive particles per lane, 256 per chunk
 
-__device__ __forceinline__ heavy_t load_heavy(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
-                                              const uint32_t *__restrict__ skip, uint32_t base, uint32_t end)
+struct chunk_t { uint4 key; pm_frac f[4]; };
+
+// Chunk at `base` (a multiple of 4): lane l holds particles base + 4 l .. + 3.  A group of four that
+// begins before `end` is loaded whole (key[] and frac[] are allocated three entries beyond the
+// capacity); what lies outside the run is ignored later.
+__device__ __forceinline__ chunk_t load_chunk(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
+                                              uint32_t base, uint32_t end)
 {
-    heavy_t t{};
-    t.sk = 1u;                                          // past the end: neither adds nor heads a piece
-    const uint32_t r = base + lane_id();
-    if (r < end) { t.sk = skip[r]; t.key = key[r]; t.f = F[r]; }
-    return t;
-}
-
-constexpr int HEAD_LIST = 128;      // entries of a wave's list of piece heads (flushed at 64; a pass adds at most 64)
-
-// Adds the sums of the listed pieces: entry = (first particle, cell k).
-__device__ __forceinline__ void flush_heads(const uint2 *list, uint32_t cnt, const double *__restrict__ pre_lo,
-                                            const double *__restrict__ pre_hi, int G, double *acc)
-{
-    pmfft::wave_sync();
-    for (uint32_t e = lane_id(); e < cnt; e += 64) {
-        const uint2 h = list[e];
-        const double lo = pre_lo[h.x], hi = pre_hi[h.x];
-        lds_add(&acc[h.y], lo);
-        lds_add(&acc[(h.y + 1 == (uint32_t)G) ? 0 : h.y + 1], hi);
+    chunk_t c{};
+    const uint32_t r = base + 4u * lane_id();
+    if (r < end) {
+        c.key = *(const uint4 *)(key + r);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c.f[t] = F[r + t];
     }
-    pmfft::wave_sync();
+    return c;
 }
 
-// Particles [beg, end) of one source row into the LDS row `acc`, 64 per pass, three passes ahead in
-// flight (the inner loop is unrolled by four so that a pass stays in the registers it was loaded
-// into).  Light particles add their own masses; the first particle of a piece is put on the wave's
-// list `heads`, and the listed pieces' sums are fetched and added 64 at a time; the other particles of
-// a piece do nothing.  When a pass ends inside a piece that reaches beyond the passes in flight, the
-// walk restarts at the end of the piece.
-__device__ __forceinline__ void deposit_heavy_run(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
-                                                  const uint32_t *__restrict__ skip, const double *__restrict__ pre, int64_t cap,
-                                                  uint32_t beg, uint32_t end, int di, int dj, int G, double *acc, uint2 *heads)
+// Particles [beg, end) of the source row whose cell 0 has key `key0` into the LDS row `acc`.
+__device__ __forceinline__ void deposit_chunks(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
+                                               uint32_t beg, uint32_t end, uint32_t key0, bool di, bool dj,
+                                               int G, double *acc)
 {
+    if (beg >= end) return;
     const int lane = lane_id();
-    const double *pre_lo = pre + (int64_t)(di + 2 * dj) * cap, *pre_hi = pre + (int64_t)(di + 2 * dj + 4) * cap;
-    uint32_t cnt = 0;
-    // returns where to go on: the next pass, or past a long piece
-    auto pass = [&](const heavy_t &a, uint32_t base) -> uint32_t {
-        const int kc = (int)(a.key % (uint32_t)G);
-        int k = 0x7fffffff - lane;
-        double lo = 0.0, hi = 0.0;
-        const bool light = a.sk == 0u;
-        if (light) {
-            const double dx = (double)a.f.dx, dy = (double)a.f.dy, dz = (double)a.f.dz;
-            const double w = (double)a.f.m * (di ? dx : 1.0 - dx) * (dj ? dy : 1.0 - dy);
-            k = kc; lo = w * (1.0 - dz); hi = w * dz;
+    const int idle = 0x7fffffff - lane;
+    uint32_t base = beg & ~3u;
+    chunk_t cur = load_chunk(F, key, base, end);
+    while (base < end) {                                        // wave-uniform
+        const chunk_t c = cur;
+        if (base + 256 < end) cur = load_chunk(F, key, base + 256, end);     // in flight while this chunk is summed
+        const uint32_t r = base + 4u * lane;
+        const uint32_t kk[4] = {c.key.x, c.key.y, c.key.z, c.key.w};
+        int ck = idle;
+        double slo = 0.0, shi = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool valid = r + t >= beg && r + t < end;
+            int k = idle;
+            double lo = 0.0, hi = 0.0;
+            if (valid) { k = (int)(kk[t] - key0); corner_pair(c.f[t], di, dj, lo, hi); }
+            if (k == ck) {
+                slo += lo; shi += hi;
+            } else {
+                if (ck != idle) {                               // the cell has changed: what was summed goes to LDS
+                    lds_add(&acc[ck], slo);
+                    lds_add(&acc[(ck + 1 == G) ? 0 : ck + 1], shi);
+                }
+                ck = k; slo = lo; shi = hi;
+            }
         }
-        add_pass(acc, G, k, lo, hi, light);
-        const bool head = (a.sk & SKIP_HEAD) != 0u;
-        const unsigned long long hm = __ballot(head);
-        if (hm) {
-            if (head) heads[cnt + __popcll(hm & ((1ull << lane) - 1ull))] = make_uint2(base + lane, (uint32_t)kc);
-            cnt += (uint32_t)__popcll(hm);
-            if (cnt >= 64) { flush_heads(heads, cnt, pre_lo, pre_hi, G, acc); cnt = 0; }
-        }
-        const uint32_t past = __shfl(a.sk, 63) & ~SKIP_HEAD;       // > 1 when the pass ends inside a piece
-        return (past >= base + 256 && past > 1u) ? past : base + 64;
-    };
-    uint32_t base = beg;
-    while (base < end) {                                        // wave-uniform throughout
-        heavy_t p0 = load_heavy(F, key, skip, base, end), p1 = load_heavy(F, key, skip, base + 64, end),
-                p2 = load_heavy(F, key, skip, base + 128, end), p3;
-        for (;;) {
-            uint32_t next;
-            p3 = load_heavy(F, key, skip, base + 192, end);
-            next = pass(p0, base);
-            if (next != base + 64 || next >= end) { base = next; break; }
-            base = next;
-            p0 = load_heavy(F, key, skip, base + 192, end);
-            next = pass(p1, base);
-            if (next != base + 64 || next >= end) { base = next; break; }
-            base = next;
-            p1 = load_heavy(F, key, skip, base + 192, end);
-            next = pass(p2, base);
-            if (next != base + 64 || next >= end) { base = next; break; }
-            base = next;
-            p2 = load_heavy(F, key, skip, base + 192, end);
-            next = pass(p3, base);
-            if (next != base + 64 || next >= end) { base = next; break; }
-            base = next;
-        }
+        add_pass(acc, G, ck, slo, shi, ck != idle);
+        base += 256;
     }
-    if (cnt) flush_heads(heads, cnt, pre_lo, pre_hi, G, acc);
 }
 
 // A summed row leaves the kernel either as G float32 densities (SPECTRUM = false) or, for G = 512,
@@ -571,13 +431,15 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
     }
 }
 
-// One wave per density row; rows for k_deposit_heavy are only listed.
+// One wave per density row; rows cut into units are only listed: entry = (row, index of its first
+// unit).  One 64-bit counter hands out the list slot (high word) and the unit index (low word)
+// together, so the entries are in the order of their unit indices.
 template <bool SPECTRUM>
 __global__ void __launch_bounds__(BLOCK)
-k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint8_t *__restrict__ row_flag,
+k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
                const uint32_t *__restrict__ rs, float *__restrict__ density,
                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
-               uint32_t *__restrict__ heavy_rows, uint32_t *__restrict__ heavy_count, pm_geom g)
+               uint2 *__restrict__ heavy_rows, unsigned long long *__restrict__ heavy_count, pm_geom g)
 {
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then 512 twiddles if SPECTRUM
     const int G = g.G;
@@ -590,95 +452,104 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, 
     }
     if (row >= R) return;
     double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
-    const row_runs t = runs_of(rs, row_flag, row, G);
-    if (t.longest > HEAVY_RUN || t.flagged) {
-        if (lane_id() == 0) {
-            const uint32_t shard = row % ROW_SHARDS;        // holds at most R / ROW_SHARDS + 1 rows
-            heavy_rows[(size_t)shard * (R / ROW_SHARDS + 1) + atomicAdd(heavy_count + shard * COUNTER_STRIDE, 1u)] = row;
-        }
-        return;
-    }
+    const row_runs t = runs_of(rs, row, G);
     if (t.longest == 0) {
         emit_empty_row<SPECTRUM>(density, spectrum, row, G, g.Ghp);
         return;
     }
     const packed_runs p(t);
-    const light_t first = p.load(F, key, 0);
-    for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
-    deposit_light(F, key, p, first, G, acc);
+    if (p.total > LIGHT_MAX) {
+        if (lane_id() == 0) {
+            const unsigned long long units = (p.total + UNIT - 1) / UNIT;
+            const unsigned long long old = atomicAdd(heavy_count, (1ull << 32) | units);
+            heavy_rows[old >> 32] = make_uint2(row, (uint32_t)old);
+        }
+        return;
+    }
+    if (p.total <= PACKED_MAX) {
+        const light_t first = p.load(F, key, 0);
+        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+        deposit_packed(F, key, p, first, G, acc);
+    } else {
+        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) deposit_chunks(F, key, t.beg[q], t.end[q], t.key0[q], q & 1, q & 2, G, acc);
+    }
     pmfft::wave_sync();
     emit_row<SPECTRUM>(acc, tw, density, spectrum, row, G, g.Ghp);
 }
 
-// Listed rows: a block of 4*S waves; wave w walks slice w/4 of run w%4 into its own LDS row, and the
-// rows are added in wave order.
-template <bool SPECTRUM>
-__global__ void __launch_bounds__(1024)
-k_deposit_heavy(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ skip,
-                const uint8_t *__restrict__ row_flag, const double *__restrict__ pre, int64_t cap, const uint32_t *__restrict__ rs,
-                float *__restrict__ density, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
-                const uint32_t *__restrict__ heavy_rows, const uint32_t *__restrict__ heavy_count, pm_geom g)
+// One wave per unit: particles [u * UNIT, (u + 1) * UNIT) of a listed row's packed sequence, summed
+// into the wave's LDS row and written out as G doubles.
+__global__ void __launch_bounds__(BLOCK)
+k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ rs,
+                const uint2 *__restrict__ heavy_rows, const unsigned long long *__restrict__ heavy_count,
+                double *__restrict__ partial, pm_geom g)
 {
-    extern __shared__ double lds_rows[];    // per wave a row of G doubles, then per wave a head list, then 512 twiddles if SPECTRUM
+    extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles
     const int G = g.G;
-    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6;
-    const int q = w & 3, slice = w >> 2, slices = nw >> 2;
-    double *acc = lds_rows + (size_t)w * G;
-    uint2 *heads = (uint2 *)(lds_rows + (size_t)nw * G) + (size_t)w * HEAD_LIST;
-    float2 *tw = (float2 *)((uint2 *)(lds_rows + (size_t)nw * G) + (size_t)nw * HEAD_LIST);
-    if constexpr (SPECTRUM)
-        for (int c = threadIdx.x; c < 512; c += blockDim.x) tw[c] = twiddle[c];
-    // blocks s, s + ROW_SHARDS, ... serve shard s
-    const uint32_t shard = blockIdx.x % ROW_SHARDS;
-    const uint32_t cnt = heavy_count[shard * COUNTER_STRIDE];
-    heavy_rows += (size_t)shard * ((uint32_t)G * (uint32_t)G / ROW_SHARDS + 1);
-    for (uint32_t e = blockIdx.x / ROW_SHARDS; e < cnt; e += gridDim.x / ROW_SHARDS) {
-        const uint32_t row = heavy_rows[e];
-        const row_runs t = runs_of(rs, row_flag, row, G);
-        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
-        // slices are whole multiples of 64 particles
-        uint32_t len = t.end[q] - t.beg[q];
-        uint32_t sl = ((len + slices - 1) / slices + 63u) & ~63u;
-        uint32_t b = t.beg[q] + (uint32_t)slice * sl, e2 = b + sl;
-        if (b > t.end[q]) b = t.end[q];
-        if (e2 > t.end[q]) e2 = t.end[q];
-        deposit_heavy_run(F, key, skip, pre, cap, b, e2, q & 1, q >> 1, G, acc, heads);
-        __syncthreads();
-        // column c of the block's rows, added in wave order, lands in row 0
-        for (int c = threadIdx.x; c < G; c += blockDim.x) {
-            double sum = 0.0;
-            for (int v = 0; v < nw; ++v) sum += lds_rows[(size_t)v * G + c];
-            lds_rows[c] = sum;
+    double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
+    const unsigned long long count = *heavy_count;
+    const uint32_t entries = (uint32_t)(count >> 32), units = (uint32_t)count;
+    const uint32_t waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t u = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); u < units; u += waves) {
+        uint32_t lo = 0, hi = entries;                  // the last entry whose first unit is <= u
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (heavy_rows[mid].y <= u) lo = mid; else hi = mid;
         }
-        __syncthreads();
-        if (w == 0) emit_row<SPECTRUM>(lds_rows, tw, density, spectrum, row, G, g.Ghp);
-        __syncthreads();
+        const uint2 entry = heavy_rows[lo];
+        const row_runs t = runs_of(rs, entry.x, G);
+        const uint32_t from = (u - entry.y) * UNIT, to = from + UNIT;      // in the packed sequence
+        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+        uint32_t off = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t len = t.end[q] - t.beg[q];
+            const uint32_t a = from > off ? from - off : 0u, b = to - off < len ? to - off : len;    // to > off always matters only when a < b
+            if (to > off && a < b) deposit_chunks(F, key, t.beg[q] + a, t.beg[q] + b, t.key0[q], q & 1, q & 2, G, acc);
+            off += len;
+        }
+        pmfft::wave_sync();
+        double *out = partial + (size_t)u * G;
+        for (int c = lane_id(); c < G; c += 64) out[c] = acc[c];
+        pmfft::wave_sync();
     }
 }
 
-// The rows k_deposit_heavy<.., false> left in a scratch mesh as float32, transformed along z into the
-// half spectrum: one wave per listed row.
+// One block per listed row: its units' rows added in unit order (a thread per column, four loads in
+// flight), then emitted like any other row.
+template <bool SPECTRUM>
 __global__ void __launch_bounds__(BLOCK)
-k_heavy_rows_r2c(const float *__restrict__ rows, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
-                 const uint32_t *__restrict__ heavy_rows, const uint32_t *__restrict__ heavy_count, int G, int pitch)
+k_sum_units(const uint32_t *__restrict__ rs, const uint2 *__restrict__ heavy_rows, const unsigned long long *__restrict__ heavy_count,
+            const double *__restrict__ partial, float *__restrict__ density, float2 *__restrict__ spectrum,
+            const float2 *__restrict__ twiddle, pm_geom g)
 {
-    __shared__ float2 tw[512];
-    __shared__ float2 bufs[BLOCK / 64][256];
-    const int j = lane_id(), w = threadIdx.x >> 6;
-    for (int q = threadIdx.x; q < 512; q += BLOCK) tw[q] = twiddle[q];
-    __syncthreads();
-    const uint32_t shard = blockIdx.x % ROW_SHARDS;
-    const uint32_t cnt = heavy_count[shard * COUNTER_STRIDE];
-    heavy_rows += (size_t)shard * ((uint32_t)G * (uint32_t)G / ROW_SHARDS + 1);
-    const uint32_t waves = (gridDim.x / ROW_SHARDS) * (BLOCK / 64);
-    for (uint32_t e = (blockIdx.x / ROW_SHARDS) * (BLOCK / 64) + w; e < cnt; e += waves) {
-        const uint32_t row = heavy_rows[e];
-        const float2 *src = (const float2 *)(rows + (size_t)row * G);
-        float2 v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = src[j + 64 * r];
-        pmfft::wave_fft256<-1>(v, bufs[w], tw, j);
-        pmfft::wave_r2c_split512(v, bufs[w], tw, j, spectrum + (size_t)row * pitch);
+    extern __shared__ double lds_rows[];                // one row of G doubles, then 512 twiddles if SPECTRUM
+    const int G = g.G;
+    float2 *tw = (float2 *)(lds_rows + G);
+    if constexpr (SPECTRUM) {
+        for (int q = threadIdx.x; q < 512; q += BLOCK) tw[q] = twiddle[q];
+    }
+    const uint32_t entries = (uint32_t)(*heavy_count >> 32);
+    for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
+        const uint2 entry = heavy_rows[e];
+        const packed_runs p(runs_of(rs, entry.x, G));
+        const uint32_t units = (p.total + UNIT - 1) / UNIT;
+        for (int c = threadIdx.x; c < G; c += BLOCK) {
+            const double *in = partial + (size_t)entry.y * G + c;
+            double sum = 0.0;
+            uint32_t u = 0;
+            for (; u + 4 <= units; u += 4, in += 4 * (size_t)G) {
+                const double v0 = in[0], v1 = in[G], v2 = in[2 * (size_t)G], v3 = in[3 * (size_t)G];
+                sum += v0; sum += v1; sum += v2; sum += v3;
+            }
+            for (; u < units; ++u, in += G) sum += in[0];
+            lds_rows[c] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) emit_row<SPECTRUM>(lds_rows, tw, density, spectrum, entry.x, G, g.Ghp);
+        __syncthreads();
     }
 }
 
@@ -854,15 +725,10 @@ static hipError_t settle_velocities(pm_ctx *c)
 hipError_t pm_launch_reorder(pm_ctx *c)
 {
     int64_t n = c->n;
-    hipError_t e = hipMemsetAsync(c->counters, 0, PM_NUM_COUNTERS * sizeof(uint32_t), c->stream);     // heavy rows, heavy-cell pieces
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(c->row_flag, 0, (size_t)c->g.G * c->g.G, c->stream);
-    if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     int u = c->cur, w = 1 - u;
-    const uint32_t cap = pm_piece_shard_cap(c->cap);
-    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, c->key_out, c->skip, c->row_flag, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
-    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, c->key_out, c->skip, c->row_flag, c->piece_list, c->counters + PM_PIECE_COUNTERS, cap, n, c->g);
+    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g);
+    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g);
     c->cur = w;
     c->v_stale = true;
     return hipGetLastError();
@@ -877,47 +743,30 @@ hipError_t pm_launch_row_start(pm_ctx *c)
     return hipGetLastError();
 }
 
-uint32_t pm_piece_shard_cap(int64_t cap)
+// A listed row is fed by more than LIGHT_MAX particles, and every particle feeds four rows.
+size_t pm_heavy_row_entries(int G, int64_t cap)
 {
-    uint32_t blocks = (uint32_t)((cap + BLOCK - 1) / BLOCK);
-    return ((blocks + PIECE_SHARDS - 1) / PIECE_SHARDS) * PIECES_PER_BLOCK;
+    const size_t by_particles = (size_t)(4 * cap / LIGHT_MAX) + 1, rows = (size_t)G * G;
+    return by_particles < rows ? by_particles : rows;
 }
 
-size_t pm_piece_list_entries(int64_t cap) { return (size_t)pm_piece_shard_cap(cap) * PIECE_SHARDS; }
-size_t pm_heavy_row_entries(int G) { return ((size_t)G * G / ROW_SHARDS + 1) * ROW_SHARDS; }
-
-static int heavy_waves(int G)
-{
-    int nw = (int)((128u * 1024u) / ((size_t)G * sizeof(double) + HEAD_LIST * sizeof(uint2))) & ~3;     // a multiple of 4: waves per run
-    return nw > PM_HEAVY_WAVES ? PM_HEAVY_WAVES : (nw < 4 ? 4 : nw);
-}
+// Units: one per UNIT particles of a listed row, plus at most one partly filled unit per row.
+size_t pm_unit_rows(int G, int64_t cap) { return (size_t)(4 * cap / UNIT) + pm_heavy_row_entries(G, cap); }
 
 template <bool SPECTRUM>
 static hipError_t deposit_dispatch(pm_ctx *c)
 {
     const int G = c->g.G;
     const uint32_t R = (uint32_t)G * (uint32_t)G;
-    hipError_t e = hipMemsetAsync(c->counters, 0, PM_PIECE_COUNTERS * sizeof(uint32_t), c->stream);     // heavy rows; the piece counts stay
+    hipError_t e = hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream);
     if (e != hipSuccess) return e;
-    k_heavy_pieces<<<PIECE_SHARDS * 32, BLOCK, 0, c->stream>>>(c->frac, c->key_out, c->piece_list, c->counters + PM_PIECE_COUNTERS,
-                                                             pm_piece_shard_cap(c->cap), c->pre, c->skip, c->n, c->cap);
     const size_t tw_bytes = SPECTRUM ? 512 * sizeof(float2) : 0;
-    const size_t lds_light = (size_t)(BLOCK / 64) * G * sizeof(double) + tw_bytes;
-    k_deposit_rows<SPECTRUM><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_light, c->stream>>>(
-        c->frac, c->key_out, c->row_flag, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
-    const int nw = heavy_waves(G);
-    const size_t lds_heavy = (size_t)nw * (G * sizeof(double) + HEAD_LIST * sizeof(uint2));
-    // heavy rows always leave as float32 rows of the density mesh; in spectrum mode a small kernel transforms them
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute((const void *)k_deposit_heavy<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    k_deposit_heavy<false><<<PM_HEAVY_GRID, nw * 64, lds_heavy, c->stream>>>(c->frac, c->key_out, c->skip, c->row_flag, c->pre, c->cap, c->row_start, c->density,
-                                                                   c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
-    if (SPECTRUM)
-        k_heavy_rows_r2c<<<ROW_SHARDS * 16, BLOCK, 0, c->stream>>>(c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, G, c->g.Ghp);
+    const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
+    k_deposit_rows<SPECTRUM><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
+        c->frac, c->key_out, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
+    k_deposit_units<<<PM_UNIT_GRID, BLOCK, lds_rows, c->stream>>>(c->frac, c->key_out, c->row_start, c->heavy_rows, c->counters, c->unit_rows, c->g);
+    k_sum_units<SPECTRUM><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->heavy_rows, c->counters, c->unit_rows, c->density,
+                                                                        c->spectrum, c->twiddle, c->g);
     return hipGetLastError();
 }
 
