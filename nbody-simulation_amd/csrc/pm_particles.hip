@@ -159,10 +159,10 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 #define PM_PACKED_MAX 512
 #endif
 #ifndef PM_LIGHT_MAX
-#define PM_LIGHT_MAX 4096
+#define PM_LIGHT_MAX 8192
 #endif
 #ifndef PM_UNIT
-#define PM_UNIT 2048
+#define PM_UNIT 4096
 #endif
 #ifndef PM_UNIT_GRID
 #define PM_UNIT_GRID 2048
