@@ -16,6 +16,12 @@ int fail(pm_ctx *c, int code, const std::string &msg)
     return code;
 }
 
+}  // namespace
+
+void pm_set_create_error(const std::string &msg) { g_create_error = msg; }
+
+namespace {
+
 #define HIP_TRY(c, expr)                                                                     \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -125,6 +131,10 @@ void pm_destroy(pm_ctx *c)
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage); hipFree(c->diag); hipFree(c->density64);
+    hipFree(c->outbox); hipFree(c->outbox_key); hipFree(c->outbox_key2); hipFree(c->outbox_idx2); hipFree(c->outbox_offsets);
+    hipFree(c->outbox_count); hipFree(c->outbox_tmp);
+    for (rocfft_plan p : {c->slab_fwd2, c->slab_inv2, c->slab_fwdx, c->slab_invx})
+        if (p) rocfft_plan_destroy(p);
     if (c->info) rocfft_execution_info_destroy(c->info);
     if (c->fwd) rocfft_plan_destroy(c->fwd);
     if (c->inv) rocfft_plan_destroy(c->inv);
@@ -155,8 +165,9 @@ static int create_impl(pm_ctx *c)
     TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G, cap)));
     TRY(dalloc(c, &c->counters, 1));
     TRY(dalloc(c, &c->unit_rows, pm_unit_rows(G, cap) * (size_t)G));
-    TRY(dalloc(c, &c->density, M));
-    TRY(dalloc(c, &c->potential, M));
+    // a slab context keeps one more density plane and three more potential planes than it owns
+    TRY(dalloc(c, &c->density, M + (size_t)G * G));
+    TRY(dalloc(c, &c->potential, M + 3 * (size_t)G * G));
     for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
     TRY(dalloc(c, &c->spectrum, (size_t)G * G * c->g.Ghp));
     TRY(dalloc(c, &c->forces, 3 * cap));
@@ -203,6 +214,7 @@ pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device
     c->g.Ghp = c->fft_custom ? pm_fft_pitch(grid_size) : c->g.Gh;
     c->g.M = (int64_t)grid_size * grid_size * grid_size;
     c->g.L = box_size; c->g.inv = (double)grid_size / box_size; c->g.Lf = (float)box_size;
+    c->g.i0 = 0; c->g.Gs = grid_size; c->g.Gd = grid_size; c->g.lo = 0;
     c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
     if (create_impl(c) != PM_OK) {
         g_create_error = c->err;

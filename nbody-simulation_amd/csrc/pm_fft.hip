@@ -41,6 +41,7 @@ struct col_pass {
     int ncols;              // valid columns per outer index (G/2 + 1)
     int G;
     float invM;
+    int outer0;             // mesh index of outer index 0 (Green multiply)
 };
 
 // N = 512 = 8*8*8.  Thread t owns column c = t & 15 and the butterflies j = (t >> 4) + 16 b, b = 0..3.
@@ -127,7 +128,8 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
         // rows are frequencies along x; outer is the y index, col the z index (functions.py:75-86)
         const int G = p.G;
         const double invG = 1.0 / (double)G;
-        const float ky = freq(outer, G, invG), kz = freq(col, G, invG);
+        const int yy = outer + p.outer0;
+        const float ky = freq(yy, G, invG), kz = freq(col, G, invG);
         const float kyz = ky * ky;
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -136,7 +138,7 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
                 int a = jl + 16 * b + 64 * r;
                 float kx = freq(a, G, invG);
                 float k2 = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), kyz), __fmul_rn(kz, kz));
-                float scl = ((a | outer | col) == 0) ? 0.0f : __fmul_rn(__frcp_rn(k2), p.invM);
+                float scl = ((a | yy | col) == 0) ? 0.0f : __fmul_rn(__frcp_rn(k2), p.invM);
                 v[b][r].x *= scl; v[b][r].y *= scl;
             }
         __syncthreads();            // every thread has read its stage-3 inputs
@@ -293,4 +295,36 @@ hipError_t pm_launch_col_fft(pm_ctx *c, int dir)
     p.outer_stride = (int64_t)G * P; p.row_stride = P;
     if (dir < 0) return launch512<-1, false>(c, p, G * p.tiles);
     return launch512<1, false>(c, p, G * p.tiles);
+}
+
+// ---- the same passes on some planes of the mesh (slab decomposition) ------------------------------
+
+hipError_t pm_launch_row_fft_planes(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int planes)
+{
+    const int G = c->g.G;
+    const int blocks = (int)((int64_t)planes * G / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
+    if (forward) k_row_r2c512<<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle);
+    else k_row_c2r512<<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes)
+{
+    const int G = c->g.G, P = c->g.Ghp;
+    col_pass p{};
+    p.spec = spec; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS;
+    p.outer_stride = (int64_t)G * P; p.row_stride = P;
+    if (dir < 0) return launch512<-1, false>(c, p, planes * p.tiles);
+    return launch512<1, false>(c, p, planes * p.tiles);
+}
+
+// spec_t: (G, ny, Ghp), transform axis first; its rows are mesh rows y0 .. y0 + ny - 1
+hipError_t pm_launch_solve_x(pm_ctx *c, float2 *spec_t, int y0, int ny)
+{
+    const int G = c->g.G, P = c->g.Ghp;
+    col_pass p{};
+    p.spec = spec_t; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS;
+    p.invM = (float)(1.0 / (double)c->g.M);
+    p.outer_stride = P; p.row_stride = (int64_t)ny * P; p.outer0 = y0;
+    return launch512<-1, true>(c, p, ny * p.tiles);
 }

@@ -19,7 +19,15 @@ struct pm_geom {
     double L;       // box size
     double inv;     // G / L, the float64 quotient of functions.py:23
     float Lf;       // (float)L for the float32 remainder of main.py:60
+    // Slab of the mesh this context owns (the whole mesh unless it was made by pm_create_slab):
+    int i0;         // first owned plane
+    int Gs;         // owned planes; a particle is owned by the slab that holds its cell's plane i
+    int Gd;         // planes the deposit writes: G (periodic along i), or Gs + 1 (the last one belongs to the next slab)
+    int lo;         // planes of the potential buffer below plane i0 (0, or 1 in a slab)
 };
+
+// What leaves a slab: a particle's position and velocity records.
+struct pm_migrant { float x, y, z, m, vx, vy, vz; uint32_t id; };
 
 // Particle records.  A particle is two 16-byte records (32-byte ones while a coordinate is
 // float64): position + mass, and velocity + the particle's index in the caller's order.  Every
@@ -89,11 +97,28 @@ struct pm_ctx {
     float ms[PM_NSTAGES] = {};
     int calls[PM_NSTAGES] = {};
 
+    // slab decomposition (pm_create_slab)
+    bool slab = false;
+    int nslabs = 1;
+    bool slab_check = false;            // the next deposit verifies that every particle lies in the slab
+    int64_t leaving = 0;                // particles with the "not mine" key in the live set (they sort to the tail)
+    pm_migrant *outbox = nullptr;       // particles that left the slab in the last drift, in no particular order
+    uint64_t *outbox_key = nullptr, *outbox_key2 = nullptr;     // (destination slab << 32) | particle id
+    uint32_t *outbox_idx2 = nullptr;    // outbox slots in sorted order
+    uint32_t *outbox_offsets = nullptr; // first sorted entry per destination slab (nslabs + 1)
+    uint32_t *outbox_count = nullptr;   // [0] entries of outbox, [1] entries that did not fit
+    int64_t outbox_cap = 0;
+    void *outbox_tmp = nullptr;
+    size_t outbox_tmp_bytes = 0;
+    rocfft_plan slab_fwd2 = nullptr, slab_inv2 = nullptr, slab_fwdx = nullptr, slab_invx = nullptr;
+
     std::string err;
 };
 
 size_t pm_heavy_row_entries(int G, int64_t cap);
 size_t pm_unit_rows(int G, int64_t cap);
+
+void pm_set_create_error(const std::string &msg);   // what pm_last_error(NULL) reports
 
 // ---- launchers (each enqueues on ctx->stream and returns a hipError_t) ----------------------
 // stage -> records: positions (n,3) of the given dtype + masses (or ones), velocities (or zeros) + iota ids
@@ -110,6 +135,21 @@ bool pm_fft_custom_supported(int G);
 int pm_fft_pitch(int G);
 hipError_t pm_fft_upload_twiddles(pm_ctx *c);
 hipError_t pm_launch_col_fft(pm_ctx *c, int dir);
+// the same transforms on `planes` planes of a slab: z and y passes between real planes and spectrum planes, and the
+// x pass (forward, Green multiply, inverse) on the transposed spectrum (G, planes, Ghp) whose rows are y = y0 ...
+hipError_t pm_launch_row_fft_planes(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int planes);
+hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes);
+hipError_t pm_launch_solve_x(pm_ctx *c, float2 *spec_t, int y0, int ny);
+hipError_t pm_launch_add(pm_ctx *c, float *mesh, const float *other, int64_t n);
+hipError_t pm_launch_green_t(pm_ctx *c, float2 *spec_t, int y0, int ny);
+hipError_t pm_launch_transpose_pack(pm_ctx *c, const float2 *spec, float2 *out, bool unpack);
+hipError_t pm_sort_outbox(pm_ctx *c, uint32_t count);
+size_t pm_sort_outbox_tmp_bytes(int64_t cap);
+hipError_t pm_launch_pack_outbox(pm_ctx *c, uint32_t count, pm_migrant *dst);
+hipError_t pm_launch_outbox_offsets(pm_ctx *c, uint32_t count, uint32_t *offsets);
+hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count);
+hipError_t pm_launch_set_ids(pm_ctx *c, const uint32_t *ids);
+hipError_t pm_launch_export_slab(pm_ctx *c, uint32_t *ids, float *pos, float *vel);
 hipError_t pm_launch_row_fft(pm_ctx *c, bool forward);
 hipError_t pm_launch_gradient(pm_ctx *c);
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);

@@ -67,6 +67,15 @@ __device__ __forceinline__ cell_t locate(const pm_prec<TP> &p, const pm_geom &g)
     return locate((double)p.x, (double)p.y, (double)p.z, g);
 }
 
+// Sort key of a particle: its cell, counted from the first plane the context owns; one key past all
+// cells for a particle whose plane belongs to another slab.
+__device__ __forceinline__ uint32_t cell_key(const cell_t &c, const pm_geom &g)
+{
+    int il = c.i - g.i0;
+    if (g.Gs != g.G && (il < 0 || il >= g.Gs)) return (uint32_t)g.Gs * (uint32_t)g.G * (uint32_t)g.G;
+    return (uint32_t)(((int64_t)il * g.G + c.j) * g.G + c.k);
+}
+
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
 
 // ---- host copies ---------------------------------------------------------------------------
@@ -142,8 +151,7 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 {
     int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (p >= n) return;
-    cell_t c = locate(P[p], g);
-    key[p] = (uint32_t)(((int64_t)c.i * g.G + c.j) * g.G + c.k);
+    key[p] = cell_key(locate(P[p], g), g);
 }
 
 // Cell order -> storage order.  Slot r of the new storage takes the position record of old slot
@@ -263,16 +271,22 @@ __device__ __forceinline__ void add_pass(double *acc, int G, int k, double lo, d
 // (di,dj) = (0,0) (1,0) (0,1) (1,1); key0: the key of cell k = 0 of each source row.
 struct row_runs { uint32_t beg[4], end[4], key0[4], longest; };
 
-__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uint32_t row, int G)
+__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uint32_t row, const pm_geom &g)
 {
+    const int G = g.G;
     int i = (int)(row / (uint32_t)G), j = (int)(row % (uint32_t)G);
-    int im = (i == 0) ? G - 1 : i - 1, jm = (j == 0) ? G - 1 : j - 1;
+    int im = i - 1, jm = (j == 0) ? G - 1 : j - 1;
+    // periodic along i, or a slab: plane i - 1 of the first plane and plane i of the extra last plane are not here
+    bool has_i = true, has_im = true;
+    if (g.Gd == G) { if (im < 0) im = G - 1; }
+    else { has_i = i < g.Gs; has_im = i >= 1; }
     uint32_t src[4] = {(uint32_t)(i * G + j), (uint32_t)(im * G + j), (uint32_t)(i * G + jm), (uint32_t)(im * G + jm)};
     row_runs t;
     t.longest = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        t.beg[q] = rs[src[q]]; t.end[q] = rs[src[q] + 1];
+        const bool has = (q & 1) ? has_im : has_i;
+        t.beg[q] = has ? rs[src[q]] : 0u; t.end[q] = has ? rs[src[q] + 1] : 0u;
         t.key0[q] = src[q] * (uint32_t)G;
         uint32_t len = t.end[q] - t.beg[q];
         t.longest = len > t.longest ? len : t.longest;
@@ -443,7 +457,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
 {
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then 512 twiddles if SPECTRUM
     const int G = g.G;
-    const uint32_t R = (uint32_t)G * (uint32_t)G;
+    const uint32_t R = (uint32_t)g.Gd * (uint32_t)G;
     const uint32_t row = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     float2 *tw = (float2 *)(lds_rows + (size_t)(BLOCK / 64) * G);
     if constexpr (SPECTRUM) {
@@ -452,7 +466,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     }
     if (row >= R) return;
     double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
-    const row_runs t = runs_of(rs, row, G);
+    const row_runs t = runs_of(rs, row, g);
     if (t.longest == 0) {
         emit_empty_row<SPECTRUM>(density, spectrum, row, G, g.Ghp);
         return;
@@ -499,7 +513,7 @@ k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
             if (heavy_rows[mid].y <= u) lo = mid; else hi = mid;
         }
         const uint2 entry = heavy_rows[lo];
-        const row_runs t = runs_of(rs, entry.x, G);
+        const row_runs t = runs_of(rs, entry.x, g);
         const uint32_t from = (u - entry.y) * UNIT, to = from + UNIT;      // in the packed sequence
         for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
         uint32_t off = 0;
@@ -534,7 +548,7 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint2 *__restrict__ heavy_row
     const uint32_t entries = (uint32_t)(*heavy_count >> 32);
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
         const uint2 entry = heavy_rows[e];
-        const packed_runs p(runs_of(rs, entry.x, G));
+        const packed_runs p(runs_of(rs, entry.x, g));
         const uint32_t units = (p.total + UNIT - 1) / UNIT;
         for (int c = threadIdx.x; c < G; c += BLOCK) {
             const double *in = partial + (size_t)entry.y * G + c;
@@ -571,13 +585,19 @@ struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
 // corner order of functions.py:61-68 and :140-178: 000 100 010 001 110 101 011 111
 __device__ constexpr int DI[8] = {0, 1, 0, 0, 1, 1, 0, 1}, DJ[8] = {0, 0, 1, 0, 1, 0, 1, 1}, DK[8] = {0, 0, 0, 1, 0, 1, 1, 1};
 
-template <typename TP, typename TV, bool FUSED>
+// Where the particles that leave a slab go (SLAB instantiation of k_gather only).
+struct outbox_t { pm_migrant *rec; uint64_t *key; uint32_t *count; uint32_t cap; };
+
+// SLAB: the context owns planes [i0, i0 + Gs) of the mesh; phi holds them with one plane below and two
+// above (plane a of the mesh is plane a - i0 + 1 of the buffer, modulo G), and a particle whose new
+// cell lies in another slab is copied to the outbox and gets the key that sorts it behind the rest.
+template <typename TP, typename TV, bool FUSED, bool SLAB = false>
 __global__ void __launch_bounds__(BLOCK)
 k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, const pm_vrec<TV> *__restrict__ Vin,
          pm_vrec<TV> *__restrict__ Vout, const uint32_t *__restrict__ vmap,
          const float *__restrict__ gx, const float *__restrict__ gy, const float *__restrict__ gz,
          const float *__restrict__ phi, float *__restrict__ forces, uint32_t *__restrict__ key_next, int64_t n, pm_geom g,
-         double dt, bool integrate)
+         double dt, bool integrate, outbox_t ob = outbox_t{})
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
@@ -589,12 +609,19 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     const int ii[2] = {c.i, i1}, jj[2] = {c.j, j1}, kk[2] = {c.k, k1};
     float ga[2][2][2], gb[2][2][2], gc[2][2][2];        // gradient components at corner [di][dj][dk]
     const int64_t s0 = (int64_t)G * G, s1 = G;
+    // plane of the potential buffer that holds mesh plane a
+    auto plane = [&](int a) {
+        if constexpr (!SLAB) return a;
+        int l = a - g.i0 + g.lo;
+        if (l < 0) l += G; else if (l >= G) l -= G;
+        return l;
+    };
     if (FUSED) {
         // np.gradient of the potential, evaluated at the eight corners on the fly
         const bool inner = c.i >= 1 && c.i <= G - 3 && c.j >= 1 && c.j <= G - 3 && c.k >= 1 && c.k <= G - 3;
         if (inner) {
             // all eight corners are interior nodes and nothing wraps: 4 + 4 + 4 short row segments
-            const float *b = phi + ((int64_t)c.i * G + c.j) * G + c.k;
+            const float *b = phi + ((int64_t)plane(c.i) * G + c.j) * G + c.k;
             f4u ctr[2][2];                                  // phi(i+a, j+b, k-1 .. k+2)
             f2u xm[2], xp[2], ym[2], yp[2];                 // phi(i-1 | i+2, j+b, k .. k+1), phi(i+a, j-1 | j+2, k .. k+1)
 #pragma unroll
@@ -628,7 +655,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 int a = ii[DI[q]], b = jj[DJ[q]], cc = kk[DK[q]];
-                int64_t node = ((int64_t)a * G + b) * G + cc;
+                int64_t node = ((int64_t)plane(a) * G + b) * G + cc;
                 ga[DI[q]][DJ[q]][DK[q]] = diff1(phi, node, s0, a, G);
                 gb[DI[q]][DJ[q]][DK[q]] = diff1(phi, node, s1, b, G);
                 gc[DI[q]][DJ[q]][DK[q]] = diff1(phi, node, 1, cc, G);
@@ -679,7 +706,82 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     Pout[r] = o;
     // cell key of the new position, for the next step's binning
     const cell_t cn = locate(o, g);
-    key_next[r] = (uint32_t)(((int64_t)cn.i * G + cn.j) * G + cn.k);
+    const uint32_t kn = cell_key(cn, g);
+    key_next[r] = kn;
+    if constexpr (SLAB && sizeof(TV) == 4) {
+        const bool leaves = kn == (uint32_t)g.Gs * (uint32_t)G * (uint32_t)G;
+        // one counter update per wave
+        const unsigned long long lm = __ballot(leaves);
+        if (lm) {
+            const int leader = __ffsll((long long)lm) - 1;
+            uint32_t base = 0;
+            if (lane_id() == leader) base = atomicAdd(ob.count, (uint32_t)__popcll(lm));
+            base = __shfl(base, leader);
+            if (leaves) {
+                const uint32_t slot = base + (uint32_t)__popcll(lm & ((1ull << lane_id()) - 1ull));
+                if (slot < ob.cap) {
+                    ob.rec[slot] = pm_migrant{o.x, o.y, o.z, o.m, v.x, v.y, v.z, v.id};
+                    ob.key[slot] = ((uint64_t)(uint32_t)(cn.i / g.Gs) << 32) | v.id;
+                } else {
+                    atomicAdd(ob.count + 1, 1u);
+                }
+            }
+        }
+    }
+}
+
+// ---- slab decomposition: particles entering and leaving -----------------------------------------
+
+__global__ void k_set_ids(pm_vrec<float> *__restrict__ V, const uint32_t *__restrict__ ids, int64_t n)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r < n) V[r].id = ids[r];
+}
+
+// outbox entries in sorted order -> one contiguous run of records
+__global__ void k_pack_outbox(const pm_migrant *__restrict__ box, const uint32_t *__restrict__ idx, pm_migrant *__restrict__ dst, uint32_t count)
+{
+    uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r < count) dst[r] = box[idx[r]];
+}
+
+// offsets[d] = first sorted outbox entry bound for slab d or a later one, d = 0 .. nslabs
+__global__ void k_outbox_offsets(const uint64_t *__restrict__ key, uint32_t count, int nslabs, uint32_t *__restrict__ offsets)
+{
+    int d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d > nslabs) return;
+    const uint64_t target = (uint64_t)d << 32;
+    uint32_t lo = 0, hi = count;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (key[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    offsets[d] = lo;
+}
+
+// arrivals behind the live set, with their cell keys
+__global__ void k_append(const pm_migrant *__restrict__ src, pm_prec<float> *__restrict__ P, pm_vrec<float> *__restrict__ V,
+                         uint32_t *__restrict__ key, int64_t at, int64_t count, pm_geom g)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= count) return;
+    const pm_migrant m = src[r];
+    const pm_prec<float> p{m.x, m.y, m.z, m.m};
+    P[at + r] = p;
+    V[at + r] = pm_vrec<float>{m.vx, m.vy, m.vz, m.id};
+    key[at + r] = cell_key(locate(p, g), g);
+}
+
+__global__ void k_export_slab(const pm_prec<float> *__restrict__ P, const pm_vrec<float> *__restrict__ V, const uint32_t *__restrict__ vmap,
+                              uint32_t *__restrict__ ids, float *__restrict__ pos, float *__restrict__ vel, int64_t n)
+{
+    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const pm_prec<float> p = P[r];
+    const pm_vrec<float> v = V[vmap ? vmap[r] : r];
+    ids[r] = v.id;
+    pos[3 * r] = p.x; pos[3 * r + 1] = p.y; pos[3 * r + 2] = p.z;
+    vel[3 * r] = v.x; vel[3 * r + 1] = v.y; vel[3 * r + 2] = v.z;
 }
 
 }  // namespace
@@ -738,15 +840,15 @@ hipError_t pm_settle_velocities(pm_ctx *c) { return settle_velocities(c); }
 
 hipError_t pm_launch_row_start(pm_ctx *c)
 {
-    const uint32_t G = (uint32_t)c->g.G;
-    k_row_start<<<grid_for((int64_t)G * G + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, G, G * G, c->row_start);
+    const uint32_t G = (uint32_t)c->g.G, R = (uint32_t)c->g.Gs * G;      // mesh rows of the owned planes
+    k_row_start<<<grid_for((int64_t)R + 1), BLOCK, 0, c->stream>>>(c->key_out, c->n, G, R, c->row_start);
     return hipGetLastError();
 }
 
 // A listed row is fed by more than LIGHT_MAX particles, and every particle feeds four rows.
 size_t pm_heavy_row_entries(int G, int64_t cap)
 {
-    const size_t by_particles = (size_t)(4 * cap / LIGHT_MAX) + 1, rows = (size_t)G * G;
+    const size_t by_particles = (size_t)(4 * cap / LIGHT_MAX) + 1, rows = (size_t)(G + 1) * G;
     return by_particles < rows ? by_particles : rows;
 }
 
@@ -757,7 +859,7 @@ template <bool SPECTRUM>
 static hipError_t deposit_dispatch(pm_ctx *c)
 {
     const int G = c->g.G;
-    const uint32_t R = (uint32_t)G * (uint32_t)G;
+    const uint32_t R = (uint32_t)c->g.Gd * (uint32_t)G;
     hipError_t e = hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream);
     if (e != hipSuccess) return e;
     const size_t tw_bytes = SPECTRUM ? 512 * sizeof(float2) : 0;
@@ -784,7 +886,13 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
     const pm_vrec<TV> *vin = V[c->vcur];
     pm_vrec<TV> *vout = c->v_stale ? V[1 - c->vcur] : V[c->vcur];
     const uint32_t *vmap = c->v_stale ? c->src : nullptr;
-    if (fused)
+    if (c->slab) {
+        if constexpr (sizeof(TP) == 4 && sizeof(TV) == 4) {
+            const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap};
+            k_gather<float, float, true, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces,
+                                                                                    c->key_in, n, c->g, dt, integrate, ob);
+        }
+    } else if (fused)
         k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate);
     else
         k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate);
@@ -843,5 +951,41 @@ hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
     const uint32_t *vmap = c->v_stale ? c->src : nullptr;
     if (c->vel_f64) k_export_keys<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vd[c->vcur], vmap, keys, perm, c->n);
     else k_export_keys<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->key_out, c->vf[c->vcur], vmap, keys, perm, c->n);
+    return hipGetLastError();
+}
+
+// ---- slab decomposition ------------------------------------------------------------------------
+
+hipError_t pm_launch_set_ids(pm_ctx *c, const uint32_t *ids)
+{
+    if (c->n == 0) return hipSuccess;
+    k_set_ids<<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->vf[c->vcur], ids, c->n);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_pack_outbox(pm_ctx *c, uint32_t count, pm_migrant *dst)
+{
+    if (count == 0) return hipSuccess;
+    k_pack_outbox<<<grid_for(count), BLOCK, 0, c->stream>>>(c->outbox, c->outbox_idx2, dst, count);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_outbox_offsets(pm_ctx *c, uint32_t count, uint32_t *offsets)
+{
+    k_outbox_offsets<<<grid_for(c->nslabs + 1), BLOCK, 0, c->stream>>>(c->outbox_key2, count, c->nslabs, offsets);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count)
+{
+    if (count == 0) return hipSuccess;
+    k_append<<<grid_for(count), BLOCK, 0, c->stream>>>(src, c->pf[c->cur], c->vf[c->vcur], c->key_in, c->n, count, c->g);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_export_slab(pm_ctx *c, uint32_t *ids, float *pos, float *vel)
+{
+    if (c->n == 0) return hipSuccess;
+    k_export_slab<<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pf[c->cur], c->vf[c->vcur], c->v_stale ? c->src : nullptr, ids, pos, vel, c->n);
     return hipGetLastError();
 }

@@ -1,0 +1,350 @@
+// Slab decomposition: a context that owns planes [plane0, plane0 + nplanes) of the mesh and the
+// particles whose cells lie in them.  Every call here does the local part of one stage of the step;
+// what has to cross between slabs (the extra density plane, the transposes of the half spectrum
+// around the x transform, the potential planes next to the slab, the particles that drift out)
+// goes through device buffers the caller owns and exchanges.  Calls that fill or read such a buffer
+// return after the work on the context's stream has finished.
+#include "pm_internal.hpp"
+
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+int fail(pm_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail((c), e_ == hipErrorOutOfMemory ? PM_ENOMEM : PM_EHIP,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+#define FFT_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        rocfft_status s_ = (expr);                                                           \
+        if (s_ != rocfft_status_success)                                                     \
+            return fail((c), PM_EFFT, std::string(#expr) + ": rocfft status " + std::to_string((int)s_)); \
+    } while (0)
+
+#define TRY(expr) do { int r_ = (expr); if (r_ != PM_OK) return r_; } while (0)
+
+int need_slab(pm_ctx *c)
+{
+    if (!c) return PM_EINVAL;
+    if (!c->slab) return fail(c, PM_ESTATE, "not a slab context: make it with pm_create_slab");
+    return PM_OK;
+}
+
+int bits_for(int64_t M)
+{
+    int b = 1;
+    while (((int64_t)1 << b) < M) ++b;
+    return b;
+}
+
+// rocFFT plans for grid sizes the hand-written kernels do not cover: batched 2-D real transforms of
+// the owned planes, and the 1-D complex transform along x of the transposed spectrum (G, Gs, Ghp).
+int make_plans(pm_ctx *c)
+{
+    const size_t G = (size_t)c->g.G, Gs = (size_t)c->g.Gs, P = (size_t)c->g.Ghp;
+    rocfft_plan_description d = nullptr;
+    const size_t len2[2] = {G, G};                                  // fastest axis first
+    size_t rs[2] = {1, G}, cs[2] = {1, P}, off[1] = {0};
+    FFT_TRY(c, rocfft_plan_description_create(&d));
+    FFT_TRY(c, rocfft_plan_description_set_data_layout(d, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, off, off,
+                                                       2, rs, G * G, 2, cs, G * P));
+    FFT_TRY(c, rocfft_plan_create(&c->slab_fwd2, rocfft_placement_notinplace, rocfft_transform_type_real_forward, rocfft_precision_single,
+                                  2, len2, Gs, d));
+    rocfft_plan_description_destroy(d);
+    FFT_TRY(c, rocfft_plan_description_create(&d));
+    FFT_TRY(c, rocfft_plan_description_set_data_layout(d, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, off, off,
+                                                       2, cs, G * P, 2, rs, G * G));
+    FFT_TRY(c, rocfft_plan_create(&c->slab_inv2, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, rocfft_precision_single,
+                                  2, len2, Gs, d));
+    rocfft_plan_description_destroy(d);
+    const size_t len1[1] = {G};
+    size_t xs[1] = {Gs * P};
+    for (int inv = 0; inv < 2; ++inv) {
+        FFT_TRY(c, rocfft_plan_description_create(&d));
+        FFT_TRY(c, rocfft_plan_description_set_data_layout(d, rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, off, off,
+                                                           1, xs, 1, 1, xs, 1));
+        FFT_TRY(c, rocfft_plan_create(inv ? &c->slab_invx : &c->slab_fwdx, rocfft_placement_inplace,
+                                      inv ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
+                                      rocfft_precision_single, 1, len1, Gs * P, d));
+        rocfft_plan_description_destroy(d);
+    }
+    size_t need = 0;
+    for (rocfft_plan p : {c->slab_fwd2, c->slab_inv2, c->slab_fwdx, c->slab_invx}) {
+        size_t w = 0;
+        FFT_TRY(c, rocfft_plan_get_work_buffer_size(p, &w));
+        need = w > need ? w : need;
+    }
+    if (need > c->fft_work_bytes) {
+        if (c->fft_work) hipFree(c->fft_work);
+        c->fft_work = nullptr;
+        HIP_TRY(c, hipMalloc(&c->fft_work, need));
+        c->fft_work_bytes = need;
+        FFT_TRY(c, rocfft_execution_info_set_work_buffer(c->info, c->fft_work, c->fft_work_bytes));
+    }
+    return PM_OK;
+}
+
+int ensure_binned(pm_ctx *c)
+{
+    if (c->binned) return PM_OK;
+    HIP_TRY(c, pm_settle_velocities(c));
+    if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
+    c->keys_fresh = false;
+    HIP_TRY(c, pm_sort_pairs(c, bits_for((int64_t)c->g.Gs * c->g.G * c->g.G + 1)));
+    HIP_TRY(c, pm_launch_reorder(c));
+    HIP_TRY(c, pm_launch_row_start(c));
+    c->n -= c->leaving;         // they carry the last key: the tail of the cell order
+    c->leaving = 0;
+    c->binned = true;
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes)
+{
+    if (nplanes < 1 || plane0 < 0 || grid_size % nplanes != 0 || plane0 % nplanes != 0 || plane0 + nplanes > grid_size ||
+        (nplanes != grid_size && nplanes + 3 > grid_size)) {
+        pm_set_create_error("pm_create_slab: nplanes must divide grid_size, plane0 must be a multiple of nplanes, and nplanes + 3 <= grid_size");
+        return nullptr;
+    }
+    // the hand-written transforms cover whole groups of 16 rows
+    if (pm_fft_custom_supported(grid_size) && ((int64_t)nplanes * grid_size) % 16 != 0) flags |= PM_FLAG_ROCFFT_ONLY;
+    pm_ctx *c = pm_create(grid_size, box_size, n_capacity, device, flags & ~(unsigned)PM_FLAG_FUSED_GRADIENT);
+    if (!c) return nullptr;
+    c->slab = true;
+    c->nslabs = grid_size / nplanes;
+    c->g.i0 = plane0; c->g.Gs = nplanes; c->g.Gd = nplanes + 1; c->g.lo = 1;
+    auto setup = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(device));
+        c->outbox_cap = c->cap / 4 + 1024;
+        HIP_TRY(c, hipMalloc((void **)&c->outbox, (size_t)c->outbox_cap * sizeof(pm_migrant)));
+        HIP_TRY(c, hipMalloc((void **)&c->outbox_key, (size_t)c->outbox_cap * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->outbox_key2, (size_t)c->outbox_cap * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->outbox_idx2, (size_t)c->outbox_cap * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->outbox_offsets, (size_t)(c->nslabs + 1) * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->outbox_count, 2 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->outbox_count, 0, 2 * sizeof(uint32_t)));
+        c->outbox_tmp_bytes = pm_sort_outbox_tmp_bytes(c->outbox_cap);
+        HIP_TRY(c, hipMalloc(&c->outbox_tmp, c->outbox_tmp_bytes + 16));
+        if (!c->fft_custom) TRY(make_plans(c));
+        return PM_OK;
+    };
+    if (setup() != PM_OK) {
+        pm_set_create_error(c->err);
+        pm_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+// pos, vel: host (n,3) float32; mass: host (n) or NULL; ids: host (n) particle numbers of the whole run
+// (they travel with the particles) or NULL for 0 .. n-1.  Every particle's cell must lie in the slab.
+int pm_slab_set_particles(pm_ctx *c, const float *pos, const float *vel, const float *mass, const uint32_t *ids, int64_t n)
+{
+    TRY(need_slab(c));
+    TRY(pm_set_particles(c, pos, PM_F32, vel, PM_F32, mass, n));
+    if (ids && n > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->stage, ids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, pm_launch_set_ids(c, (const uint32_t *)c->stage));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->leaving = 0;
+    c->slab_check = true;
+    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, 2 * sizeof(uint32_t), c->stream));
+    return PM_OK;
+}
+
+// Cloud-in-cell deposit of the owned particles into planes 0 .. nplanes of the context's density
+// (nplanes + 1 planes: the last one is plane 0 of the next slab).
+int pm_slab_deposit(pm_ctx *c)
+{
+    TRY(need_slab(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure_binned(c));
+    if (c->slab_check) {
+        uint32_t mine = 0;
+        HIP_TRY(c, hipMemcpyAsync(&mine, c->row_start + (size_t)c->g.Gs * c->g.G, sizeof(mine), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if ((int64_t)mine != c->n) return fail(c, PM_EINVAL, std::to_string(c->n - (int64_t)mine) + " particles given to this slab lie in other slabs");
+        c->slab_check = false;
+    }
+    HIP_TRY(c, pm_launch_deposit(c, false));
+    return PM_OK;
+}
+
+// Planes [first, first + count) of a mesh of the context <-> a device buffer of count*G*G floats.
+// which: PM_MESH_DENSITY (planes 0 .. nplanes) or PM_MESH_POTENTIAL (plane 0 is mesh plane plane0 - 1,
+// planes 1 .. nplanes the owned ones, then two more).  op 0: mesh -> buffer, 1: buffer -> mesh, 2: mesh += buffer.
+int pm_slab_planes(pm_ctx *c, int which, int first, int count, void *device_buffer, int op)
+{
+    TRY(need_slab(c));
+    const int limit = which == PM_MESH_DENSITY ? c->g.Gs + 1 : c->g.Gs + 3;
+    if ((which != PM_MESH_DENSITY && which != PM_MESH_POTENTIAL) || first < 0 || count < 0 || first + count > limit || !device_buffer || op < 0 || op > 2)
+        return fail(c, PM_EINVAL, "pm_slab_planes: bad mesh, plane range, buffer or op");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t plane = (size_t)c->g.G * c->g.G;
+    float *mesh = (which == PM_MESH_DENSITY ? c->density : c->potential) + (size_t)first * plane;
+    const size_t bytes = (size_t)count * plane * sizeof(float);
+    if (op == 0) HIP_TRY(c, hipMemcpyAsync(device_buffer, mesh, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else if (op == 1) HIP_TRY(c, hipMemcpyAsync(mesh, device_buffer, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(c, pm_launch_add(c, mesh, (const float *)device_buffer, (int64_t)count * (int64_t)plane));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+// dir < 0: density planes 0 .. nplanes-1 -> half spectrum (nplanes, G, pitch), transformed along z and y.
+// dir > 0: half spectrum -> potential planes 1 .. nplanes (unnormalised inverse along y and z).
+int pm_slab_fft2(pm_ctx *c, int dir)
+{
+    TRY(need_slab(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t plane = (size_t)c->g.G * c->g.G;
+    float *pot = c->potential + plane;
+    if (c->fft_custom) {
+        if (dir < 0) {
+            HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density, nullptr, c->spectrum, c->g.Gs));
+            HIP_TRY(c, pm_launch_col_fft_planes(c, -1, c->spectrum, c->g.Gs));
+        } else {
+            HIP_TRY(c, pm_launch_col_fft_planes(c, 1, c->spectrum, c->g.Gs));
+            HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, pot, c->spectrum, c->g.Gs));
+        }
+    } else {
+        void *in[1], *out[1];
+        if (dir < 0) { in[0] = c->density; out[0] = c->spectrum; FFT_TRY(c, rocfft_execute(c->slab_fwd2, in, out, c->info)); }
+        else { in[0] = c->spectrum; out[0] = pot; FFT_TRY(c, rocfft_execute(c->slab_inv2, in, out, c->info)); }
+    }
+    return PM_OK;
+}
+
+// Half spectrum of the slab -> nslabs blocks for the all-to-all (block p: rows p*nplanes .. of every
+// owned plane), and back.  The buffers hold nplanes * G * pitch complex64.
+int pm_slab_pack(pm_ctx *c, void *device_blocks)
+{
+    TRY(need_slab(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, pm_launch_transpose_pack(c, c->spectrum, (float2 *)device_blocks, false));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+int pm_slab_unpack(pm_ctx *c, const void *device_blocks)
+{
+    TRY(need_slab(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, pm_launch_transpose_pack(c, (const float2 *)device_blocks, c->spectrum, true));
+    return PM_OK;
+}
+
+// device_spectrum_t: (G, nplanes, pitch) complex64 -- every plane's rows plane0 .. plane0 + nplanes - 1, as the
+// all-to-all leaves them.  Forward transform along x, 1/k^2 and 1/M (functions.py:75-89), inverse along x, in place.
+int pm_slab_solve_x(pm_ctx *c, void *device_spectrum_t)
+{
+    TRY(need_slab(c));
+    if (!device_spectrum_t) return fail(c, PM_EINVAL, "NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float2 *s = (float2 *)device_spectrum_t;
+    if (c->fft_custom) {
+        HIP_TRY(c, pm_launch_solve_x(c, s, c->g.i0, c->g.Gs));
+    } else {
+        void *io[1] = {s};
+        FFT_TRY(c, rocfft_execute(c->slab_fwdx, io, nullptr, c->info));
+        HIP_TRY(c, pm_launch_green_t(c, s, c->g.i0, c->g.Gs));
+        FFT_TRY(c, rocfft_execute(c->slab_invx, io, nullptr, c->info));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+// force_CIC with np.gradient evaluated on the fly from the potential planes (all nplanes + 3 must be in
+// place), kick, drift, wrap (main.py:54-60).  Particles whose new cell lies in another slab go to the outbox.
+int pm_slab_gather_kick_drift(pm_ctx *c, double dt)
+{
+    TRY(need_slab(c));
+    if (!c->pf[0]) return fail(c, PM_ESTATE, "no particles");
+    if (c->pos_f64 || c->vel_f64) return fail(c, PM_ESTATE, "slab contexts hold float32 particles");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, pm_launch_gather(c, dt, true, false, true));
+    c->binned = false; c->have_forces = false; c->keys_fresh = true;
+    return PM_OK;
+}
+
+// The particles that left in the last drift, sorted by (destination slab, id), as 32-byte records
+// {x, y, z, m, vx, vy, vz, id} in device_records; counts[d] = how many go to slab d (host, nslabs entries).
+int pm_slab_outbox(pm_ctx *c, int64_t *counts, void *device_records, int64_t capacity)
+{
+    TRY(need_slab(c));
+    if (!counts) return fail(c, PM_EINVAL, "NULL counts");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t h[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, c->outbox_count, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h[1]) return fail(c, PM_ENOMEM, "outbox overflow: " + std::to_string(h[0]) + " particles left the slab in one step");
+    if ((int64_t)h[0] > capacity) return fail(c, PM_EINVAL, "device_records too small for " + std::to_string(h[0]) + " records");
+    c->leaving = h[0];
+    std::vector<uint32_t> off((size_t)c->nslabs + 1, 0u);
+    if (h[0]) {
+        if (!device_records) return fail(c, PM_EINVAL, "NULL device_records");
+        HIP_TRY(c, pm_sort_outbox(c, h[0]));
+        HIP_TRY(c, pm_launch_pack_outbox(c, h[0], (pm_migrant *)device_records));
+        HIP_TRY(c, pm_launch_outbox_offsets(c, h[0], c->outbox_offsets));
+        HIP_TRY(c, hipMemcpyAsync(off.data(), c->outbox_offsets, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    for (int d = 0; d < c->nslabs; ++d) counts[d] = (int64_t)off[d + 1] - (int64_t)off[d];
+    return PM_OK;
+}
+
+// Particles arriving from other slabs (records as pm_slab_outbox writes them) join the live set.
+int pm_slab_inbox(pm_ctx *c, const void *device_records, int64_t n)
+{
+    TRY(need_slab(c));
+    if (n < 0 || (n > 0 && !device_records)) return fail(c, PM_EINVAL, "bad inbox");
+    if (c->n + n > c->cap) return fail(c, PM_ENOMEM, "particle capacity exceeded: " + std::to_string(c->n + n) + " > " + std::to_string(c->cap));
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->v_stale) return fail(c, PM_ESTATE, "pm_slab_inbox belongs between the drift and the next deposit");
+    HIP_TRY(c, pm_launch_append(c, (const pm_migrant *)device_records, n));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n += n;
+    c->binned = false;
+    return PM_OK;
+}
+
+// Owned particles in storage order: ids (n) uint32, pos and vel (n,3) float32, host buffers of
+// pm_num_particles() entries.  Particles that have left but were not yet dropped by a deposit are included.
+int pm_slab_get_particles(pm_ctx *c, uint32_t *ids, float *pos, float *vel)
+{
+    TRY(need_slab(c));
+    if (!ids || !pos || !vel) return fail(c, PM_EINVAL, "NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n;
+    if (!n) return PM_OK;
+    uint32_t *di = (uint32_t *)c->stage;
+    float *dp = (float *)(di + n), *dv = dp + 3 * n;       // 28 n bytes of the 32 n staging bytes
+    HIP_TRY(c, pm_launch_export_slab(c, di, dp, dv));
+    HIP_TRY(c, hipMemcpyAsync(ids, di, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(pos, dp, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(vel, dv, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+// Row pitch (complex64 elements) of the half spectrum buffers of this context.
+int pm_slab_pitch(const pm_ctx *c) { return c ? c->g.Ghp : -1; }
+
+}  // extern "C"

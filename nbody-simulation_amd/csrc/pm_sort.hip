@@ -47,3 +47,21 @@ hipError_t pm_sort_pairs(pm_ctx *c, int bits)
     return nine ? sort_pairs<9>(c->sort_tmp, need, c->key_in, c->key_out, c->src, (size_t)c->n, (unsigned)bits, c->stream)
                 : sort_pairs<8>(c->sort_tmp, need, c->key_in, c->key_out, c->src, (size_t)c->n, (unsigned)bits, c->stream);
 }
+
+// Particles leaving a slab: (destination slab, particle id) keys with the outbox slot as value.
+size_t pm_sort_outbox_tmp_bytes(int64_t cap)
+{
+    size_t bytes = 0;
+    uint64_t *k = nullptr;
+    uint32_t *v = nullptr;
+    rocprim::radix_sort_pairs(nullptr, bytes, k, k, rocprim::counting_iterator<uint32_t>(0), v, (size_t)cap, 0, 64, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t pm_sort_outbox(pm_ctx *c, uint32_t count)
+{
+    if (count == 0) return hipSuccess;
+    size_t need = c->outbox_tmp_bytes;
+    return rocprim::radix_sort_pairs(c->outbox_tmp, need, c->outbox_key, c->outbox_key2, rocprim::counting_iterator<uint32_t>(0), c->outbox_idx2,
+                                     (size_t)count, 0, 64, c->stream);
+}

@@ -39,6 +39,19 @@ SIGNATURES = {
     "pm_deposit_ngp": (_int, [_c_p]),
     "pm_forces_ngp": (_int, [_c_p]),
     "pm_get_mesh_f64": (_int, [_c_p, _int, _c_p]),
+    "pm_create_slab": (_c_p, [_int, _dbl, _i64, _int, ctypes.c_uint, _int, _int]),
+    "pm_slab_set_particles": (_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _i64]),
+    "pm_slab_deposit": (_int, [_c_p]),
+    "pm_slab_planes": (_int, [_c_p, _int, _int, _int, _c_p, _int]),
+    "pm_slab_fft2": (_int, [_c_p, _int]),
+    "pm_slab_pack": (_int, [_c_p, _c_p]),
+    "pm_slab_unpack": (_int, [_c_p, _c_p]),
+    "pm_slab_solve_x": (_int, [_c_p, _c_p]),
+    "pm_slab_gather_kick_drift": (_int, [_c_p, _dbl]),
+    "pm_slab_outbox": (_int, [_c_p, _c_p, _c_p, _i64]),
+    "pm_slab_inbox": (_int, [_c_p, _c_p, _i64]),
+    "pm_slab_get_particles": (_int, [_c_p, _c_p, _c_p, _c_p]),
+    "pm_slab_pitch": (_int, [_c_p]),
     "pm_stage_times": (_int, [_c_p, _c_p, _c_p]),
     "pm_set_flags": (_int, [_c_p, ctypes.c_uint]),
     "pm_synchronize": (_int, [_c_p]),

@@ -1,0 +1,261 @@
+"""The PM step over several GPUs: one process per GPU, the mesh cut into slabs of planes along axis 0.
+
+Rank r owns mesh planes [r*Gs, (r+1)*Gs), Gs = G / world, and the particles whose cell (functions.py:27-39)
+has its i in that range.  One step of main.py:50-60 becomes
+
+    deposit (local)                    -> the extra plane goes to the next rank, which adds it
+    FFT along z, y (local)             -> all-to-all: every rank gets a range of y rows of every plane
+    FFT along x, 1/k^2, inverse x      -> all-to-all back
+    inverse FFT along y, z (local)     -> one potential plane from the previous rank, two from the next
+    gradient + gather + kick + drift   -> particles whose new cell lies in another slab move there
+
+The local work is done by an engine: `HipSlabEngine` drives libpm.so (include/pm.h, the pm_slab_* calls)
+on device buffers held as torch tensors; the exchanges are torch.distributed collectives on those tensors
+(backend "nccl" = RCCL over xGMI; with "gloo" the tensors are staged through the host).  An engine is
+anything with the methods of HipSlabEngine; the tests drive the same exchange code with a CPU engine.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def slab_of(positions, grid_size, box_size, world):
+    """Rank that owns each particle: plane i of its cell (functions.py:27-39, float64 like numba) // (G / world)."""
+    x = np.asarray(positions)[:, 0].astype(np.float64)
+    i = ((x % float(box_size)) * (grid_size / float(box_size))).astype(np.int64)
+    i[i >= grid_size] -= grid_size
+    return i // (grid_size // world)
+
+
+class HipSlabEngine:
+    """Local stages of one slab on one GPU through libpm.so."""
+
+    def __init__(self, grid_size, box_size, plane0, nplanes, capacity, device_index=0):
+        self.lib = _lib.load()
+        self.G, self.L, self.i0, self.Gs = int(grid_size), float(box_size), int(plane0), int(nplanes)
+        self.world = self.G // self.Gs
+        torch.cuda.set_device(device_index)
+        self.device = torch.device("cuda", device_index)
+        self.cap = int(capacity)
+        self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, 0, self.i0, self.Gs)
+        if not self.ctx:
+            raise _lib.PMError("pm_create_slab failed: " + (self.lib.pm_last_error(None) or b"?").decode())
+        self.pitch = self.lib.pm_slab_pitch(self.ctx)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self._planes = torch.empty((3, self.G, self.G), **f32)
+        self._blocks = [torch.empty((self.Gs * self.G * self.pitch, 2), **f32) for _ in range(2)]
+        self._records = torch.empty((self.cap // 4 + 1024, 8), **f32)
+
+    def close(self):
+        if self.ctx:
+            self.lib.pm_destroy(self.ctx)
+            self.ctx = None
+
+    def _check(self, rc):
+        _lib.check(self.ctx, rc)
+
+    def _sync(self):
+        torch.cuda.synchronize(self.device)      # tensors written by torch are read on the library's own stream
+
+    @property
+    def n(self):
+        return int(self.lib.pm_num_particles(self.ctx))
+
+    def set_particles(self, pos, vel, mass, ids):
+        pos = np.ascontiguousarray(pos, np.float32)
+        vel = np.ascontiguousarray(vel, np.float32)
+        mass = np.ascontiguousarray(mass, np.float32)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        if len(pos) > self.cap:
+            raise ValueError("more particles than the engine's capacity")
+        self._check(self.lib.pm_slab_set_particles(self.ctx, pos.ctypes.data, vel.ctypes.data, mass.ctypes.data, ids.ctypes.data, len(pos)))
+
+    def deposit(self):
+        self._check(self.lib.pm_slab_deposit(self.ctx))
+
+    def planes_out(self, which, first, count):
+        """Copy of planes [first, first+count) of the density (which=0) or potential (which=1) buffer."""
+        out = self._planes[:count]
+        self._check(self.lib.pm_slab_planes(self.ctx, which, first, count, out.data_ptr(), 0))
+        return out.clone()
+
+    def planes_in(self, which, first, planes, add=False):
+        planes = planes.to(self.device, torch.float32).contiguous()
+        self._sync()
+        self._check(self.lib.pm_slab_planes(self.ctx, which, first, planes.shape[0], planes.data_ptr(), 2 if add else 1))
+
+    def fft2(self, direction):
+        self._check(self.lib.pm_slab_fft2(self.ctx, direction))
+
+    def pack(self):
+        """The z,y-transformed slab as world blocks (world, Gs, Gs, pitch, 2) float32."""
+        self._check(self.lib.pm_slab_pack(self.ctx, self._blocks[0].data_ptr()))
+        return self._blocks[0]
+
+    def unpack(self, blocks):
+        assert blocks.is_contiguous() and blocks.device == self.device
+        self._sync()
+        self._check(self.lib.pm_slab_unpack(self.ctx, blocks.data_ptr()))
+
+    def transposed_buffer(self):
+        return self._blocks[1]
+
+    def solve_x(self, spectrum_t):
+        assert spectrum_t.is_contiguous() and spectrum_t.device == self.device
+        self._sync()
+        self._check(self.lib.pm_slab_solve_x(self.ctx, spectrum_t.data_ptr()))
+
+    def gather_kick_drift(self, dt):
+        self._check(self.lib.pm_slab_gather_kick_drift(self.ctx, float(dt)))
+
+    def outbox(self):
+        """(counts per destination rank, records (n, 8) float32) of the particles that left in the last drift."""
+        counts = (ctypes.c_int64 * self.world)()
+        self._check(self.lib.pm_slab_outbox(self.ctx, counts, self._records.data_ptr(), self._records.shape[0]))
+        counts = [int(c) for c in counts]
+        return counts, self._records[:sum(counts)]
+
+    def inbox(self, records):
+        records = records.to(self.device, torch.float32).contiguous()
+        self._sync()
+        self._check(self.lib.pm_slab_inbox(self.ctx, records.data_ptr(), records.shape[0]))
+
+    def particles(self):
+        n = self.n
+        ids, pos, vel = np.empty(n, np.uint32), np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        if n:
+            self._check(self.lib.pm_slab_get_particles(self.ctx, ids.ctypes.data, pos.ctypes.data, vel.ctypes.data))
+        return ids, pos, vel
+
+    def synchronize(self):
+        self._check(self.lib.pm_synchronize(self.ctx))
+
+
+class _Comm:
+    """all-to-all of flat float32 / int64 tensors; the only collective the step needs."""
+
+    def __init__(self, group=None):
+        self.on = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.stage_on_host = self.on and dist.get_backend(group) == "gloo"
+
+    def all_to_all(self, chunks, recv_sizes):
+        """chunks[p]: 1-D tensor for rank p; recv_sizes[p]: elements expected from rank p.  Returns the list received."""
+        dtype, device = chunks[0].dtype, chunks[0].device
+        if self.world == 1:
+            return [chunks[0].clone()]
+        send = torch.cat([c.reshape(-1) for c in chunks])
+        recv = torch.empty(int(sum(recv_sizes)), dtype=dtype, device=device)
+        if self.stage_on_host and send.is_cuda:
+            s, r = send.cpu(), torch.empty(recv.shape, dtype=dtype)
+            dist.all_to_all_single(r, s, [int(x) for x in recv_sizes], [c.numel() for c in chunks], group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, [int(x) for x in recv_sizes], [c.numel() for c in chunks], group=self.group)
+        return list(torch.split(recv, [int(x) for x in recv_sizes]))
+
+    def barrier(self):
+        if self.on:
+            dist.barrier(group=self.group)
+
+
+class SlabSimulation:
+    """main.py:50-60 over `world` slabs.  Every rank passes its own particles (see slab_of) and their
+    numbers in the whole run; `engine` defaults to HipSlabEngine on cuda:`device_index`."""
+
+    def __init__(self, grid_size, box_size, positions, velocities, masses, ids, *, group=None, device_index=0, engine=None,
+                 capacity=None):
+        self.comm = _Comm(group)
+        self.G, self.L = int(grid_size), float(box_size)
+        world, rank = self.comm.world, self.comm.rank
+        if self.G % world:
+            raise ValueError("grid_size must be a multiple of the number of ranks")
+        self.Gs = self.G // world
+        n = len(positions)
+        cap = int(capacity) if capacity else int(1.5 * n) + 4096
+        self.engine = engine if engine is not None else HipSlabEngine(self.G, self.L, rank * self.Gs, self.Gs, cap, device_index)
+        self.engine.set_particles(positions, velocities, masses, ids)
+        self.next, self.prev = (rank + 1) % world, (rank - 1) % world
+
+    def close(self):
+        self.engine.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- exchanges -----------------------------------------------------------------------------------
+
+    def _neighbours(self, to_next, to_prev, from_prev_size, from_next_size):
+        """Send flat tensors to the next and the previous rank; returns (from_prev, from_next)."""
+        world = self.comm.world
+        empty = to_next.new_empty(0)
+        chunks, sizes = [empty] * world, [0] * world
+        # with two ranks the next and the previous rank are the same one: what goes "to next" comes first
+        chunks[self.next] = to_next.reshape(-1)
+        chunks[self.prev] = torch.cat([chunks[self.prev], to_prev.reshape(-1)]) if self.prev == self.next else to_prev.reshape(-1)
+        sizes[self.prev] += from_prev_size
+        sizes[self.next] += from_next_size
+        got = self.comm.all_to_all(chunks, sizes)
+        if self.prev == self.next:
+            g = got[self.prev]
+            return g[:from_prev_size], g[from_prev_size:]
+        return got[self.prev], got[self.next]
+
+    def step(self, dt, nsteps=1):
+        for _ in range(nsteps):
+            self._step(dt)
+
+    def _step(self, dt):
+        e, G, Gs, world = self.engine, self.G, self.Gs, self.comm.world
+        plane = G * G
+        # deposit; the plane beyond the slab belongs to the next rank (functions.py:56: i1 = (i + 1) % G)
+        e.deposit()
+        ghost = e.planes_out(0, Gs, 1)
+        from_prev, _ = self._neighbours(ghost, ghost.new_empty(0), plane, 0)
+        e.planes_in(0, 0, from_prev.reshape(1, G, G), add=True)
+        # compute_potential (functions.py:73-89)
+        e.fft2(-1)
+        blocks = e.pack()
+        per_peer = blocks.numel() // world
+        got = self.comm.all_to_all(list(torch.split(blocks.reshape(-1), per_peer)), [per_peer] * world)
+        spec_t = e.transposed_buffer()
+        torch.cat(got, out=spec_t.reshape(-1))
+        e.solve_x(spec_t)
+        got = self.comm.all_to_all(list(torch.split(spec_t.reshape(-1), per_peer)), [per_peer] * world)
+        torch.cat(got, out=blocks.reshape(-1))
+        e.unpack(blocks)
+        e.fft2(+1)
+        # potential planes beside the slab: one below (from the previous rank), two above (from the next rank)
+        to_next = e.planes_out(1, Gs, 1)            # my last owned plane
+        to_prev = e.planes_out(1, 1, 2)             # my first two owned planes
+        below, above = self._neighbours(to_next, to_prev, plane, 2 * plane)
+        e.planes_in(1, 0, below.reshape(1, G, G))
+        e.planes_in(1, Gs + 1, above.reshape(2, G, G))
+        # gradient, gather, kick, drift (main.py:54-60); then the particles that changed slab
+        e.gather_kick_drift(dt)
+        counts, records = e.outbox()
+        flat = records.reshape(-1)
+        c = torch.tensor(counts, dtype=torch.int64)
+        incoming = self.comm.all_to_all([c[p:p + 1] for p in range(world)], [1] * world)
+        incoming = [int(t[0]) for t in incoming]
+        offs = np.concatenate(([0], np.cumsum(counts))) * 8
+        got = self.comm.all_to_all([flat[offs[p]:offs[p + 1]] for p in range(world)], [8 * k for k in incoming])
+        arrivals = torch.cat(got).reshape(-1, 8)
+        e.inbox(arrivals)
+
+    def particles(self):
+        """(ids, positions, velocities) of the particles this rank owns now."""
+        return self.engine.particles()
+
+    def synchronize(self):
+        self.engine.synchronize()
+        self.comm.barrier()
