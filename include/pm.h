@@ -154,7 +154,9 @@ int pm_slab_gather_kick_drift(pm_ctx *ctx, double dt);
  * pm_slab_gather_kick_drift and the next pm_slab_deposit, outbox first. */
 int pm_slab_outbox(pm_ctx *ctx, int64_t *counts, void *device_records, int64_t capacity);
 int pm_slab_inbox(pm_ctx *ctx, const void *device_records, int64_t n);
-/* Owned particles in storage order: ids (n), pos and vel (n,3), n = pm_num_particles(). */
+/* Owned particles in storage order: ids (n), pos and vel (n,3); the buffers hold pm_num_particles() entries as
+ * it is before the call, and pm_num_particles() after the call says how many were written (the particles
+ * that left in the last drift are not among them). */
 int pm_slab_get_particles(pm_ctx *ctx, uint32_t *ids, float *pos, float *vel);
 /* Row pitch, in complex64 elements, of the half-spectrum buffers above (>= G/2 + 1). */
 int pm_slab_pitch(const pm_ctx *ctx);

@@ -613,7 +613,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     auto plane = [&](int a) {
         if constexpr (!SLAB) return a;
         int l = a - g.i0 + g.lo;
-        if (l < 0) l += G; else if (l >= G) l -= G;
+        if (l < 0) l += G; else if (l > g.Gs + 2) l -= G;       // the buffer holds planes 0 .. Gs + 2
         return l;
     };
     if (FUSED) {

@@ -325,13 +325,15 @@ int pm_slab_inbox(pm_ctx *c, const void *device_records, int64_t n)
     return PM_OK;
 }
 
-// Owned particles in storage order: ids (n) uint32, pos and vel (n,3) float32, host buffers of
-// pm_num_particles() entries.  Particles that have left but were not yet dropped by a deposit are included.
+// Owned particles in storage order: ids (n) uint32, pos and vel (n,3) float32, host buffers of at least
+// pm_num_particles() entries as it was before the call; afterwards pm_num_particles() says how many were
+// written (particles that left in the last drift are dropped here at the latest).
 int pm_slab_get_particles(pm_ctx *c, uint32_t *ids, float *pos, float *vel)
 {
     TRY(need_slab(c));
     if (!ids || !pos || !vel) return fail(c, PM_EINVAL, "NULL buffer");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->leaving) TRY(ensure_binned(c));
     const size_t n = (size_t)c->n;
     if (!n) return PM_OK;
     uint32_t *di = (uint32_t *)c->stage;

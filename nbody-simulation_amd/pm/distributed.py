@@ -129,7 +129,8 @@ class HipSlabEngine:
         ids, pos, vel = np.empty(n, np.uint32), np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
         if n:
             self._check(self.lib.pm_slab_get_particles(self.ctx, ids.ctypes.data, pos.ctypes.data, vel.ctypes.data))
-        return ids, pos, vel
+        n = self.n                      # without the particles that left in the last drift
+        return ids[:n], pos[:n], vel[:n]
 
     def synchronize(self):
         self._check(self.lib.pm_synchronize(self.ctx))
@@ -143,7 +144,8 @@ class _Comm:
         self.group = group
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
-        self.stage_on_host = self.on and dist.get_backend(group) == "gloo"
+        self.backend = dist.get_backend(group) if self.on else None
+        self.stage_on_host = self.backend == "gloo"        # gloo moves host memory: device tensors are staged
 
     def all_to_all(self, chunks, recv_sizes):
         """chunks[p]: 1-D tensor for rank p; recv_sizes[p]: elements expected from rank p.  Returns the list received."""
@@ -151,6 +153,9 @@ class _Comm:
         if self.world == 1:
             return [chunks[0].clone()]
         send = torch.cat([c.reshape(-1) for c in chunks])
+        if self.backend == "nccl" and not send.is_cuda:     # RCCL moves device memory only (the particle counts are host integers)
+            got = self.all_to_all([c.cuda() for c in chunks], recv_sizes)
+            return [t.cpu() for t in got]
         recv = torch.empty(int(sum(recv_sizes)), dtype=dtype, device=device)
         if self.stage_on_host and send.is_cuda:
             s, r = send.cpu(), torch.empty(recv.shape, dtype=dtype)
