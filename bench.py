@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--no-fused-gradient", action="store_true")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
+                    help="--gpus N > 1: N independent replicas of the workload (default), or ONE run of the workload with the "
+                         "mesh cut into N slabs (all-to-all transposes, halo planes and particle migration over RCCL)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,8 +159,12 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run for --gpus > 1")
 
+    if args.parallelism == "slab":
+        import torch                              # noqa: F401  (its HIP runtime has to be the one libpm.so binds to)
     import pm                                     # loads libpm.so (raises if it is missing)
     pm.load()
+    if args.parallelism == "slab":
+        return slab_main(args, rank, world, local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist          # rendezvous and barriers only
@@ -222,6 +229,56 @@ def main():
         print(json.dumps(out), flush=True)
     sim.close()
     if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def slab_main(args, rank, world, local_rank):
+    """ONE simulation of the workload, the mesh cut into `world` slabs: strong scaling."""
+    import torch
+    import torch.distributed as dist
+    from pm.distributed import SlabSimulation, slab_of
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n, G, L = args.n, args.grid, BOX
+    pos, vel, mass = make_workload(args.workload, n, L, 1052)
+    mine = slab_of(pos, G, L, world) == rank
+    ids = np.arange(n, dtype=np.uint32)[mine]
+    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids, device_index=local_rank, capacity=int(mine.sum() * 1.3) + (1 << 20))
+    n_local = int(mine.sum())
+    del pos, vel, mass
+
+    sim.step(DT, args.warmup)
+    sim.synchronize()
+    t0 = time.perf_counter()
+    sim.step(DT, args.steps)
+    sim.synchronize()
+    elapsed = time.perf_counter() - t0
+    loads = [n_local]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        l = torch.zeros(world, dtype=torch.int64, device="cuda")
+        l[rank] = n_local
+        dist.all_reduce(l)
+        loads = [int(x) for x in l]
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        b_step = 64 * n + 80 * G ** 3
+        ach = b_step / (ms_step * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "particle-updates/sec per PM step (N=16M, 512^3 mesh)", "value": n * args.steps / elapsed,
+            "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {G // world} planes",
+                       "particles_per_slab_at_start": loads},
+            "roofline": {"bound": "hbm", "kernel": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                         "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None, "algorithmic_bytes_per_launch": b_step,
+                         "ms_per_launch": ms_step}}), flush=True)
+    sim.close()
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
