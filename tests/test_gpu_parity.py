@@ -223,6 +223,42 @@ def test_full_size_properties(pm):
         assert np.abs(sim.velocities() - vo).max() <= 1e-5 * np.abs(vo).max()
 
 
+def test_headline_size_properties(pm):
+    """The headline configuration itself (two-galaxy collision, N = 16,777,216 on 512^3) through properties that do
+    not need the oracle at that size: mass conservation of the deposit, sortedness and completeness of the cell order,
+    the same bits from the fused and the staged pipeline and from two runs, no net force on the system (Newton's third
+    law holds for CIC deposit + CIC gather of a centred-difference gradient up to the one-sided faces, which the
+    galaxies do not touch), and the oracle on a 200k-particle sample of the same positions for the gathered forces."""
+    import bench
+    n, G, L, dt = 16_777_216, 512, 10000, 0.005
+    pos, vel, mass = bench.make_workload("two_galaxy", n, L, 1052)
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=False) as sim:
+        keys, perm = sim.cell_keys()
+        assert np.all(np.diff(keys) >= 0)
+        assert np.array_equal(np.bincount(perm, minlength=n), np.ones(n, np.int64))
+        sample = np.random.default_rng(0).choice(n, 200_000, replace=False)
+        assert np.array_equal(keys[np.argsort(perm)[sample]], O.cell_keys(pos[sample], G, L))
+        sim.deposit()
+        d = sim.density()
+        assert abs(d.astype(np.float64).sum() - n) <= 1e-6 * n
+        sim.solve_potential()
+        sim.gradient()
+        sim.compute_forces()
+        f = sim.forces()
+        grad = [sim.mesh(w) for w in (2, 3, 4)]
+        fo = O.force_CIC(grad, pos[sample], G, L)
+        assert np.array_equal(f[sample], fo)                            # same gradient meshes: bit for bit
+        net = f.astype(np.float64).sum(axis=0)
+        assert np.abs(net).max() <= 1e-5 * np.abs(f.astype(np.float64)).sum(axis=0).max()
+        sim.set_particles(pos, vel, mass)
+        sim.step(dt, 2)
+        x_staged, v_staged = sim.positions(), sim.velocities()
+    for _ in range(2):
+        with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+            sim.step(dt, 2)
+            assert np.array_equal(sim.positions(), x_staged) and np.array_equal(sim.velocities(), v_staged)
+
+
 def test_single_fourier_mode(pm):
     """A single density mode delta gives delta / k^2 with k in cycles per sample (functions.py:75-85)."""
     from pm import functions as F
