@@ -5,6 +5,13 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#ifndef PM_SORT_BLOCK
+#define PM_SORT_BLOCK 1024
+#endif
+#ifndef PM_SORT_ITEMS
+#define PM_SORT_ITEMS 8
+#endif
+
 namespace {
 
 // One pass over the pairs per "place" of RADIX bits.  The library's tuned default is 8 bits; with
@@ -13,7 +20,7 @@ namespace {
 template <unsigned RADIX>
 using sort_config = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, RADIX,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<PM_SORT_BLOCK, PM_SORT_ITEMS>, RADIX,
                                         rocprim::block_radix_rank_algorithm::match>>;
 
 template <unsigned RADIX>

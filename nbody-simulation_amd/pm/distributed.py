@@ -46,7 +46,6 @@ class HipSlabEngine:
             raise _lib.PMError("pm_create_slab failed: " + (self.lib.pm_last_error(None) or b"?").decode())
         self.pitch = self.lib.pm_slab_pitch(self.ctx)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self._planes = torch.empty((3, self.G, self.G), **f32)
         self._blocks = [torch.empty((self.Gs * self.G * self.pitch, 2), **f32) for _ in range(2)]
         self._records = torch.empty((self.cap // 4 + 1024, 8), **f32)
 
@@ -59,7 +58,9 @@ class HipSlabEngine:
         _lib.check(self.ctx, rc)
 
     def _sync(self):
-        torch.cuda.synchronize(self.device)      # tensors written by torch are read on the library's own stream
+        # The library works on its own stream: before it reads or writes a tensor, everything torch has queued on
+        # that tensor (copies, cats, collectives) has to be done.  The library's calls wait for their own work.
+        torch.cuda.synchronize(self.device)
 
     @property
     def n(self):
@@ -79,9 +80,10 @@ class HipSlabEngine:
 
     def planes_out(self, which, first, count):
         """Copy of planes [first, first+count) of the density (which=0) or potential (which=1) buffer."""
-        out = self._planes[:count]
+        out = torch.empty((count, self.G, self.G), dtype=torch.float32, device=self.device)
+        self._sync()
         self._check(self.lib.pm_slab_planes(self.ctx, which, first, count, out.data_ptr(), 0))
-        return out.clone()
+        return out
 
     def planes_in(self, which, first, planes, add=False):
         planes = planes.to(self.device, torch.float32).contiguous()
@@ -93,6 +95,7 @@ class HipSlabEngine:
 
     def pack(self):
         """The z,y-transformed slab as world blocks (world, Gs, Gs, pitch, 2) float32."""
+        self._sync()
         self._check(self.lib.pm_slab_pack(self.ctx, self._blocks[0].data_ptr()))
         return self._blocks[0]
 
@@ -115,6 +118,7 @@ class HipSlabEngine:
     def outbox(self):
         """(counts per destination rank, records (n, 8) float32) of the particles that left in the last drift."""
         counts = (ctypes.c_int64 * self.world)()
+        self._sync()
         self._check(self.lib.pm_slab_outbox(self.ctx, counts, self._records.data_ptr(), self._records.shape[0]))
         counts = [int(c) for c in counts]
         return counts, self._records[:sum(counts)]
