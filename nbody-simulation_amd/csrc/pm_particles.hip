@@ -13,6 +13,9 @@ namespace {
 constexpr int BLOCK = 256;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// index of the wave in its block, as a value the compiler knows to be the same in all lanes (so that
+// what is computed from it stays in scalar registers and is loaded through the scalar cache)
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // Python-style x % L for L > 0 (functions.py:27-29): result in [0, L].
 __device__ __forceinline__ double wrap_f64(double x, double L)
@@ -458,14 +461,14 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then 512 twiddles if SPECTRUM
     const int G = g.G;
     const uint32_t R = (uint32_t)g.Gd * (uint32_t)G;
-    const uint32_t row = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t row = blockIdx.x * (BLOCK / 64) + (uint32_t)wave_id();
     float2 *tw = (float2 *)(lds_rows + (size_t)(BLOCK / 64) * G);
     if constexpr (SPECTRUM) {
         for (int q = threadIdx.x; q < 512; q += BLOCK) tw[q] = twiddle[q];
         __syncthreads();                                // the only block-wide barrier: before any wave leaves
     }
     if (row >= R) return;
-    double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
+    double *acc = lds_rows + (size_t)wave_id() * G;
     const row_runs t = runs_of(rs, row, g);
     if (t.longest == 0) {
         emit_empty_row<SPECTRUM>(density, spectrum, row, G, g.Ghp);
@@ -502,11 +505,11 @@ k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
 {
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles
     const int G = g.G;
-    double *acc = lds_rows + (size_t)(threadIdx.x >> 6) * G;
+    double *acc = lds_rows + (size_t)wave_id() * G;
     const unsigned long long count = *heavy_count;
     const uint32_t entries = (uint32_t)(count >> 32), units = (uint32_t)count;
     const uint32_t waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t u = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); u < units; u += waves) {
+    for (uint32_t u = blockIdx.x * (BLOCK / 64) + (uint32_t)wave_id(); u < units; u += waves) {
         uint32_t lo = 0, hi = entries;                  // the last entry whose first unit is <= u
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
