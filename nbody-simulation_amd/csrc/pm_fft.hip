@@ -4,15 +4,15 @@
 // transformed along j and along i by these kernels, in place.  Both are strided ("column")
 // transforms: the transform axis has a large stride and the neighbouring columns are contiguous
 // in memory, so a workgroup takes a tile of COLS = 16 neighbouring columns (128 contiguous bytes
-// per row) by all N rows, keeps it in LDS (N*16*8 bytes = 64 KiB at N = 512) and runs a
-// radix-8 Stockham FFT on the 16 columns side by side.  Every global access of a wave is four
+// per row) by all N rows, keeps it in LDS (N*16*8 bytes = 64 KiB at N = 512, 128 KiB at N = 1024) and
+// runs a Stockham FFT (radix 8, 8, 8 or 16, 8, 8) on the 16 columns side by side.  Every global access of a wave is four
 // full 128-byte lines; every LDS access of a 16-lane group is one 128-byte row (conflict free).
 //
 // The pass along i is fused: forward FFT, Green's-function multiply (functions.py:75-86) with
 // the 1/M of the inverse transform (functions.py:89), inverse FFT, one read and one write of the
 // spectrum instead of three.  That works without an extra exchange because a thread of the
-// Stockham schedule ends the forward transform holding exactly the rows (n + 64 r) that the
-// first inverse stage starts from.
+// Stockham schedule ends the forward transform holding exactly the rows that its first inverse
+// stage starts from.
 #include "pm_internal.hpp"
 #include "pm_fft_dev.hpp"
 
@@ -44,13 +44,27 @@ struct col_pass {
     int outer0;             // mesh index of outer index 0 (Green multiply)
 };
 
-// N = 512 = 8*8*8.  Thread t owns column c = t & 15 and the butterflies j = (t >> 4) + 16 b, b = 0..3.
-// Every stage reads rows j + 64 r (r = 0..7); stage s writes rows expand(j) + r * 8^s.
-template <int DIR, bool GREEN>
-__global__ void __launch_bounds__(FFT_BLOCK, 2)
-k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
+// Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 8 at N = 512, 16 at N = 1024).  A column is
+// worked on by TPC = N / 32 threads, each holding 32 of its elements; a block is 16 columns = 16 TPC threads.
+template <int N> struct col_plan {
+    static constexpr int R1 = N / 64;                   // first radix
+    static constexpr int TPC = N / 32;                  // threads per column
+    static constexpr int THREADS = COLS * TPC;
+    static constexpr int NB1 = (N / R1) / TPC;          // butterflies per thread in stage 1
+    static constexpr int NB = (N / 8) / TPC;            // ... in stages 2 and 3 (= 4)
+    static constexpr size_t LDS_BYTES = (size_t)(N * COLS + N) * sizeof(float2);
+};
+
+// Thread t owns column c = t & 15; jl = t >> 4 is its place among the column's threads.  Stage 1
+// (radix R1, no twiddles) takes butterflies j = jl + TPC b and rows j + 64 r; stages 2 and 3 (radix 8)
+// take j = jl + TPC b and rows j + (N/8) r.  After stage 3 the thread holds the rows jl + TPC m, m < 32:
+// exactly the inputs of its stage-1 butterflies, which is what lets the Green pass turn round in registers.
+template <int N, int DIR, bool GREEN>
+__global__ void __launch_bounds__(col_plan<N>::THREADS, N == 512 ? 2 : 1)
+k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 {
-    constexpr int N = 512, NB = 4;
+    using plan = col_plan<N>;
+    constexpr int R1 = plan::R1, TPC = plan::TPC, NB1 = plan::NB1, NB = plan::NB, Q = N / 8;
     extern __shared__ float2 lds[];                 // [N][COLS] tile, then the N twiddles
     float2 *tile = lds;
     float2 *tw = lds + N * COLS;
@@ -60,26 +74,26 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
     const bool valid = col < p.ncols;
     float2 *g = p.spec + (int64_t)outer * p.outer_stride + col;
 
-    for (int q = t; q < N; q += FFT_BLOCK) tw[q] = twiddle[q];
+    for (int q = t; q < N; q += plan::THREADS) tw[q] = twiddle[q];
 
-    float2 v[NB][8];
-    // ---- stage 1 (Ns = 1): from global, no twiddles
+    float2 v[32];
+    // ---- stage 1 inputs from global: v[b * R1 + r] = row jl + TPC b + 64 r
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB1; ++b)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            int row = jl + 16 * b + 64 * r;
-            v[b][r] = valid ? g[(int64_t)row * p.row_stride] : make_float2(0.0f, 0.0f);
+        for (int r = 0; r < R1; ++r) {
+            int row = jl + TPC * b + 64 * r;
+            v[b * R1 + r] = valid ? g[(int64_t)row * p.row_stride] : make_float2(0.0f, 0.0f);
         }
 
     auto stage1_out = [&](auto dir) {
         constexpr int D = decltype(dir)::value;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            fft8<D>(v[b]);
-            int j = jl + 16 * b;
+        for (int b = 0; b < NB1; ++b) {
+            fft_r<R1, D>(v + b * R1);
+            int j = jl + TPC * b;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) tile[(8 * j + r) * COLS + c] = v[b][r];
+            for (int r = 0; r < R1; ++r) tile[(R1 * j + r) * COLS + c] = v[b * R1 + r];
         }
     };
     auto stage2 = [&](auto dir) {
@@ -87,17 +101,17 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[b][r] = tile[(jl + 16 * b + 64 * r) * COLS + c];
+            for (int r = 0; r < 8; ++r) v[b * 8 + r] = tile[(jl + TPC * b + Q * r) * COLS + c];
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            int j = jl + 16 * b, k = j & 7;
+            int j = jl + TPC * b, k = j & (R1 - 1);
 #pragma unroll
-            for (int r = 1; r < 8; ++r) v[b][r] = cmul(v[b][r], twid<D>(tw[8 * r * k]));
-            fft8<D>(v[b]);
-            int j0 = (j >> 3) * 64 + k;
+            for (int r = 1; r < 8; ++r) v[b * 8 + r] = cmul(v[b * 8 + r], twid<D>(tw[8 * r * k]));       // N / (R1 * 8) = 8
+            fft8<D>(v + b * 8);
+            int j0 = (j / R1) * (R1 * 8) + k;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) tile[(j0 + 8 * r) * COLS + c] = v[b][r];
+            for (int r = 0; r < 8; ++r) tile[(j0 + R1 * r) * COLS + c] = v[b * 8 + r];
         }
     };
     auto stage3 = [&](auto dir) {
@@ -105,13 +119,13 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[b][r] = tile[(jl + 16 * b + 64 * r) * COLS + c];
+            for (int r = 0; r < 8; ++r) v[b * 8 + r] = tile[(jl + TPC * b + Q * r) * COLS + c];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            int j = jl + 16 * b;
+            int j = jl + TPC * b;
 #pragma unroll
-            for (int r = 1; r < 8; ++r) v[b][r] = cmul(v[b][r], twid<D>(tw[r * j]));
-            fft8<D>(v[b]);          // v[b][r] is now element j + 64 r of the transform
+            for (int r = 1; r < 8; ++r) v[b * 8 + r] = cmul(v[b * 8 + r], twid<D>(tw[r * j]));
+            fft8<D>(v + b * 8);          // v[b * 8 + r] is now element j + (N/8) r of the transform
         }
     };
     using dir_t = std::integral_constant<int, DIR>;
@@ -135,12 +149,20 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                int a = jl + 16 * b + 64 * r;
+                int a = jl + TPC * b + Q * r;
                 float kx = freq(a, G, invG);
                 float k2 = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), kyz), __fmul_rn(kz, kz));
                 float scl = ((a | yy | col) == 0) ? 0.0f : __fmul_rn(__frcp_rn(k2), p.invM);
-                v[b][r].x *= scl; v[b][r].y *= scl;
+                v[b * 8 + r].x *= scl; v[b * 8 + r].y *= scl;
             }
+        if constexpr (R1 != 8) {
+            // from "row jl + TPC (b + 4 r)" to the stage-1 order "row jl + TPC (b' + NB1 r')"
+            float2 u[32];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) u[(m % NB1) * R1 + m / NB1] = v[(m % NB) * 8 + m / NB];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) v[m] = u[m];
+        }
         __syncthreads();            // every thread has read its stage-3 inputs
         stage1_out(inv_t{});
         __syncthreads();
@@ -154,102 +176,113 @@ k_col_fft512(col_pass p, const float2 *__restrict__ twiddle)
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                int row = jl + 16 * b + 64 * r;
-                g[(int64_t)row * p.row_stride] = v[b][r];
+                int row = jl + TPC * b + Q * r;
+                g[(int64_t)row * p.row_stride] = v[b * 8 + r];
             }
     }
 }
 
 // ---- z axis: real <-> half-complex transforms of contiguous rows ----------------------------------
 //
-// One wave per mesh row.  A row of N = 512 reals is read as 256 complex numbers z[n] = x[2n] + i x[2n+1],
-// transformed by a 256-point radix-4 Stockham FFT (one butterfly per lane per stage, lane j always
-// reading elements j + 64 r), and split into the 257 values of the half spectrum:
-//   X[k] = (Z[k] + conj Z[256-k])/2 - (i/2) w^k (Z[k] - conj Z[256-k]),   w = exp(-2 pi i / 512).
+// One wave per mesh row.  A row of N reals is read as M = N/2 complex numbers z[n] = x[2n] + i x[2n+1],
+// transformed by an M-point Stockham FFT (one butterfly per lane per stage, lane j always reading
+// elements j + 64 r; radix 4 at N = 512, radix 8 at N = 1024), and split into the M + 1 values of the
+// half spectrum:
+//   X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) w^k (Z[k] - conj Z[M-k]),   w = exp(-2 pi i / N).
 // The inverse runs the same steps backwards:
-//   Z[k] = (X[k] + conj X[256-k]) + i w^-k (X[k] - conj X[256-k]),  z = unnormalised inverse FFT of Z.
+//   Z[k] = (X[k] + conj X[M-k]) + i w^-k (X[k] - conj X[M-k]),  z = unnormalised inverse FFT of Z.
 // Every global access of a wave is a contiguous 512-byte run.
 
 constexpr int ROWS_PER_WAVE = 4;
 
+template <int N>
 __global__ void __launch_bounds__(FFT_BLOCK)
-k_row_r2c512(const float *__restrict__ in, float2 *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
+k_row_r2c(const float *__restrict__ in, float2 *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
 {
-    __shared__ float2 tw[512];
-    __shared__ float2 bufs[FFT_BLOCK / 64][256];
+    constexpr int E = N / 128, M = N / 2;
+    __shared__ float2 tw[N];
+    __shared__ float2 bufs[FFT_BLOCK / 64][M];
     const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
     float2 *buf = bufs[w];
-    for (int q = threadIdx.x; q < 512; q += FFT_BLOCK) tw[q] = twiddle[q];
+    for (int q = threadIdx.x; q < N; q += FFT_BLOCK) tw[q] = twiddle[q];
     __syncthreads();
     const int64_t row0 = ((int64_t)blockIdx.x * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-        const float2 *src = (const float2 *)(in + (row0 + rr) * 512);
-        float2 v[4];
+        const float2 *src = (const float2 *)(in + (row0 + rr) * N);
+        float2 v[E];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = src[j + 64 * r];
-        wave_fft256<-1>(v, buf, tw, j);
-        wave_r2c_split512(v, buf, tw, j, out + (row0 + rr) * pitch);
+        for (int r = 0; r < E; ++r) v[r] = src[j + 64 * r];
+        wave_fft<E, -1>(v, buf, tw, j);
+        wave_r2c_split<E>(v, buf, tw, j, out + (row0 + rr) * pitch);
     }
 }
 
+template <int N>
 __global__ void __launch_bounds__(FFT_BLOCK)
-k_row_c2r512(const float2 *__restrict__ in, float *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
+k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
 {
-    __shared__ float2 tw[512];
-    __shared__ float2 bufs[FFT_BLOCK / 64][260];
+    constexpr int E = N / 128, M = N / 2;
+    __shared__ float2 tw[N];
+    __shared__ float2 bufs[FFT_BLOCK / 64][M + 4];
     const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
     float2 *buf = bufs[w];
-    for (int q = threadIdx.x; q < 512; q += FFT_BLOCK) tw[q] = twiddle[q];
+    for (int q = threadIdx.x; q < N; q += FFT_BLOCK) tw[q] = twiddle[q];
     __syncthreads();
     const int64_t row0 = ((int64_t)blockIdx.x * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
         const float2 *src = in + (row0 + rr) * pitch;
-        float2 x[4];
+        float2 x[E], v[E];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = src[j + 64 * r];
-        float2 xn = (j == 0) ? src[256] : make_float2(0.0f, 0.0f);
-        wave_sync();
+        for (int r = 0; r < E; ++r) x[r] = src[j + 64 * r];
+        const float2 xm = (j == 0) ? src[M] : make_float2(0.0f, 0.0f);
+        wave_c2r_merge<E>(x, xm, v, buf, tw, j);
+        wave_fft<E, 1>(v, buf, tw, j);
+        float2 *dst = (float2 *)(out + (row0 + rr) * N);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) buf[j + 64 * r] = x[r];
-        if (j == 0) buf[256] = xn;
-        wave_sync();
-        float2 v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = j + 64 * r;
-            float2 xk = x[r], xp = buf[256 - k];
-            if (k == 0) { xk.y = 0.0f; xp.y = 0.0f; }                      // X[0] and X[256] of a real row are real
-            const float2 e = make_float2(xk.x + xp.x, xk.y - xp.y);        // X[k] + conj X[256-k]
-            const float2 d = make_float2(xk.x - xp.x, xk.y + xp.y);        // X[k] - conj X[256-k]
-            const float2 wk = tw[k];
-            const float2 t = cmul(make_float2(wk.x, -wk.y), d);            // w^-k d
-            v[r] = make_float2(e.x - t.y, e.y + t.x);                      // e + i t
-        }
-        wave_fft256<1>(v, buf, tw, j);
-        float2 *dst = (float2 *)(out + (row0 + rr) * 512);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[j + 64 * r] = v[r];
+        for (int r = 0; r < E; ++r) dst[j + 64 * r] = v[r];
     }
 }
 
-constexpr size_t LDS_BYTES_512 = (512 * COLS + 512) * sizeof(float2);
-
-template <int DIR, bool GREEN>
-hipError_t launch512(pm_ctx *c, const col_pass &p, int blocks)
+template <int N, int DIR, bool GREEN>
+hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
 {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_col_fft512<DIR, GREEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_512);
+        hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    k_col_fft512<DIR, GREEN><<<blocks, FFT_BLOCK, LDS_BYTES_512, c->stream>>>(p, c->twiddle);
+    k_col_fft<N, DIR, GREEN><<<blocks, col_plan<N>::THREADS, col_plan<N>::LDS_BYTES, c->stream>>>(p, c->twiddle);
+    return hipGetLastError();
+}
+
+// dir < 0 forward, > 0 inverse, 0: forward, Green multiply, inverse
+hipError_t launch_col_any(pm_ctx *c, int dir, const col_pass &p, int blocks)
+{
+    if (c->g.G == 512) {
+        if (dir == 0) return launch_col<512, -1, true>(c, p, blocks);
+        return dir < 0 ? launch_col<512, -1, false>(c, p, blocks) : launch_col<512, 1, false>(c, p, blocks);
+    }
+    if (dir == 0) return launch_col<1024, -1, true>(c, p, blocks);
+    return dir < 0 ? launch_col<1024, -1, false>(c, p, blocks) : launch_col<1024, 1, false>(c, p, blocks);
+}
+
+hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int64_t rows)
+{
+    const int blocks = (int)(rows / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
+    if (c->g.G == 512) {
+        if (forward) k_row_r2c<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle);
+        else k_row_c2r<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle);
+    } else {
+        if (forward) k_row_r2c<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle);
+        else k_row_c2r<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle);
+    }
     return hipGetLastError();
 }
 
 }  // namespace
 
-bool pm_fft_custom_supported(int G) { return G == 512; }
+bool pm_fft_custom_supported(int G) { return G == 512 || G == 1024; }
 
 int pm_fft_pitch(int G)
 {
@@ -274,57 +307,48 @@ hipError_t pm_fft_upload_twiddles(pm_ctx *c)
 // z axis: density (G,G,G) -> half spectrum (forward), half spectrum -> potential (inverse)
 hipError_t pm_launch_row_fft(pm_ctx *c, bool forward)
 {
-    const int G = c->g.G;
-    const int blocks = (int)((int64_t)G * G / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
-    if (forward) k_row_r2c512<<<blocks, FFT_BLOCK, 0, c->stream>>>(c->density, c->spectrum, c->g.Ghp, c->twiddle);
-    else k_row_c2r512<<<blocks, FFT_BLOCK, 0, c->stream>>>(c->spectrum, c->potential, c->g.Ghp, c->twiddle);
-    return hipGetLastError();
+    return launch_rows(c, forward, c->density, c->potential, c->spectrum, (int64_t)c->g.G * c->g.G);
+}
+
+static col_pass pass_for(pm_ctx *c, float2 *spec)
+{
+    const int G = c->g.G, P = c->g.Ghp;
+    col_pass p{};
+    p.spec = spec; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS;
+    p.invM = (float)(1.0 / (double)c->g.M);
+    return p;
 }
 
 // dir < 0: forward along j.  dir > 0: inverse along j.  dir == 0: forward along i, Green multiply, inverse along i.
 hipError_t pm_launch_col_fft(pm_ctx *c, int dir)
 {
     const int G = c->g.G, P = c->g.Ghp;
-    col_pass p{};
-    p.spec = c->spectrum; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS;
-    p.invM = (float)(1.0 / (double)c->g.M);
-    if (dir == 0) {
-        p.outer_stride = P; p.row_stride = (int64_t)G * P;
-        return launch512<-1, true>(c, p, G * p.tiles);
-    }
-    p.outer_stride = (int64_t)G * P; p.row_stride = P;
-    if (dir < 0) return launch512<-1, false>(c, p, G * p.tiles);
-    return launch512<1, false>(c, p, G * p.tiles);
+    col_pass p = pass_for(c, c->spectrum);
+    if (dir == 0) { p.outer_stride = P; p.row_stride = (int64_t)G * P; }
+    else { p.outer_stride = (int64_t)G * P; p.row_stride = P; }
+    return launch_col_any(c, dir, p, G * p.tiles);
 }
 
 // ---- the same passes on some planes of the mesh (slab decomposition) ------------------------------
 
 hipError_t pm_launch_row_fft_planes(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int planes)
 {
-    const int G = c->g.G;
-    const int blocks = (int)((int64_t)planes * G / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
-    if (forward) k_row_r2c512<<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle);
-    else k_row_c2r512<<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle);
-    return hipGetLastError();
+    return launch_rows(c, forward, real_in, real_out, spec, (int64_t)planes * c->g.G);
 }
 
 hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes)
 {
     const int G = c->g.G, P = c->g.Ghp;
-    col_pass p{};
-    p.spec = spec; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS;
+    col_pass p = pass_for(c, spec);
     p.outer_stride = (int64_t)G * P; p.row_stride = P;
-    if (dir < 0) return launch512<-1, false>(c, p, planes * p.tiles);
-    return launch512<1, false>(c, p, planes * p.tiles);
+    return launch_col_any(c, dir < 0 ? -1 : 1, p, planes * p.tiles);
 }
 
 // spec_t: (G, ny, Ghp), transform axis first; its rows are mesh rows y0 .. y0 + ny - 1
 hipError_t pm_launch_solve_x(pm_ctx *c, float2 *spec_t, int y0, int ny)
 {
-    const int G = c->g.G, P = c->g.Ghp;
-    col_pass p{};
-    p.spec = spec_t; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS;
-    p.invM = (float)(1.0 / (double)c->g.M);
+    const int P = c->g.Ghp;
+    col_pass p = pass_for(c, spec_t);
     p.outer_stride = P; p.row_stride = (int64_t)ny * P; p.outer0 = y0;
-    return launch512<-1, true>(c, p, ny * p.tiles);
+    return launch_col_any(c, 0, p, ny * p.tiles);
 }

@@ -11,8 +11,17 @@ namespace pmfft {
 // transformed through either kernel has the same bits.
 #define PM_FFT_FUSE _Pragma("clang fp contract(fast)")
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// (the adds too: a product made in one helper fuses into the add made in another only if both allow it)
+__device__ __forceinline__ float2 cadd(float2 a, float2 b)
+{
+    PM_FFT_FUSE
+    return make_float2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ float2 csub(float2 a, float2 b)
+{
+    PM_FFT_FUSE
+    return make_float2(a.x - b.x, a.y - b.y);
+}
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     PM_FFT_FUSE
@@ -51,6 +60,40 @@ template <int DIR> __device__ __forceinline__ void fft4(float2 *v)
     v[0] = cadd(a0, a1); v[2] = csub(a0, a1); v[1] = cadd(a2, a3); v[3] = csub(a2, a3);
 }
 
+// 16-point DFT, in place, natural order in and out: 4 x 4 with the twiddles w16^(r c) between the two passes.
+template <int DIR> __device__ __forceinline__ void fft16(float2 *v)
+{
+    PM_FFT_FUSE
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    float2 t[4][4];                                     // t[c][r]: column c = n mod 4 holds n = c + 4 r
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[c][r] = v[c + 4 * r];
+        fft4<DIR>(t[c]);                                // t[c][k1], k1 = 0..3
+    }
+    // t[c][k1] *= w16^(c k1), w16 = exp(DIR * 2 pi i / 16)
+    const float2 w1 = make_float2(c1, DIR < 0 ? -s1 : s1), w2 = make_float2(h, DIR < 0 ? -h : h), w3 = make_float2(s1, DIR < 0 ? -c1 : c1);
+    const float2 w6 = make_float2(-h, DIR < 0 ? -h : h), w9 = make_float2(-c1, DIR < 0 ? s1 : -s1);
+    t[1][1] = cmul(t[1][1], w1); t[1][2] = cmul(t[1][2], w2); t[1][3] = cmul(t[1][3], w3);
+    t[2][1] = cmul(t[2][1], w2); t[2][2] = rot90<DIR>(t[2][2]); t[2][3] = cmul(t[2][3], w6);
+    t[3][1] = cmul(t[3][1], w3); t[3][2] = cmul(t[3][2], w6); t[3][3] = cmul(t[3][3], w9);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        float2 u[4] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1]};
+        fft4<DIR>(u);                                   // u[k2]: output k = k1 + 4 k2
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = u[k2];
+    }
+}
+
+template <int R, int DIR> __device__ __forceinline__ void fft_r(float2 *v)
+{
+    if constexpr (R == 4) fft4<DIR>(v);
+    else if constexpr (R == 8) fft8<DIR>(v);
+    else fft16<DIR>(v);
+}
+
 // Orders the LDS accesses of one wave: what its lanes wrote before is visible to all its lanes
 // after.  The LDS serves a wave's requests in issue order, so no instruction is needed, only that
 // the compiler keeps the accesses on their side of this point.
@@ -61,53 +104,91 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 256-point FFT of the values a wave holds as v[r] = element (lane + 64 r); result in the same form.
-// `buf` is the wave's own 256-element LDS exchange buffer, `tw` the table exp(-2 pi i q / 512) in LDS,
-// j the lane.  Radix-4 Stockham: one butterfly per lane per stage, every stage reads elements j + 64 r.
-template <int DIR>
-__device__ __forceinline__ void wave_fft256(float2 *v, float2 *buf, const float2 *tw, int j)
+// M-point FFT, M = 64 E, of the values a wave holds as v[r] = element (lane + 64 r), r < E; result in
+// the same form.  `buf` is the wave's own M-element LDS exchange buffer, `tw` the table
+// exp(-2 pi i q / (2 M)) in LDS, j the lane.  Radix-E Stockham (E = 4: four stages, E = 8: three):
+// one butterfly per lane per stage, every stage reads elements j + 64 r.
+template <int E, int DIR>
+__device__ __forceinline__ void wave_fft(float2 *v, float2 *buf, const float2 *tw, int j)
 {
-    fft4<DIR>(v);                                       // stage 1, Ns = 1: no twiddles
+    constexpr int LOG = E == 4 ? 2 : 3, STAGES = E == 4 ? 4 : 3;
+    fft_r<E, DIR>(v);                                   // stage 1, Ns = 1: no twiddles
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) buf[4 * j + r] = v[r];
+    for (int r = 0; r < E; ++r) buf[E * j + r] = v[r];
 #pragma unroll
-    for (int s = 1; s < 4; ++s) {                       // Ns = 4, 16, 64
-        const int Ns = 1 << (2 * s), k = j & (Ns - 1), step = 128 >> (2 * s);
+    for (int s = 1; s < STAGES; ++s) {                  // Ns = E, E^2, ...
+        const int Ns = 1 << (LOG * s), k = j & (Ns - 1), step = (2 * 64) >> (LOG * s);     // 2 M / (Ns E)
         wave_sync();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = buf[j + 64 * r];
+        for (int r = 0; r < E; ++r) v[r] = buf[j + 64 * r];
 #pragma unroll
-        for (int r = 1; r < 4; ++r) v[r] = cmul(v[r], twid<DIR>(tw[r * k * step]));
-        fft4<DIR>(v);
-        if (s < 3) {
+        for (int r = 1; r < E; ++r) v[r] = cmul(v[r], twid<DIR>(tw[r * k * step]));
+        fft_r<E, DIR>(v);
+        if (s < STAGES - 1) {
             wave_sync();
-            const int j0 = ((j >> (2 * s)) << (2 * s + 2)) + k;
+            const int j0 = ((j >> (LOG * s)) << (LOG * s + LOG)) + k;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) buf[j0 + r * Ns] = v[r];
+            for (int r = 0; r < E; ++r) buf[j0 + r * Ns] = v[r];
         }
     }
 }
 
-// A wave holds the 256-point transform Z of a packed real row (z[n] = x[2n] + i x[2n+1]) as
-// v[r] = Z[j + 64 r]; writes the 257 values X[0..256] of the row's half spectrum to dst:
-//   X[k] = (Z[k] + conj Z[256-k])/2 - (i/2) w^k (Z[k] - conj Z[256-k]),   w = exp(-2 pi i / 512).
-__device__ __forceinline__ void wave_r2c_split512(const float2 *v, float2 *buf, const float2 *tw, int j, float2 *__restrict__ dst)
+template <int DIR>
+__device__ __forceinline__ void wave_fft256(float2 *v, float2 *buf, const float2 *tw, int j) { wave_fft<4, DIR>(v, buf, tw, j); }
+
+// A wave holds the M-point transform Z of a packed real row of 2 M values (z[n] = x[2n] + i x[2n+1]) as
+// v[r] = Z[j + 64 r]; writes the M + 1 values X[0..M] of the row's half spectrum to dst:
+//   X[k] = (Z[k] + conj Z[M-k])/2 - (i/2) w^k (Z[k] - conj Z[M-k]),   w = exp(-2 pi i / (2 M)).
+template <int E>
+__device__ __forceinline__ void wave_r2c_split(const float2 *v, float2 *buf, const float2 *tw, int j, float2 *__restrict__ dst)
 {
     PM_FFT_FUSE
+    constexpr int M = 64 * E;
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) buf[j + 64 * r] = v[r];
+    for (int r = 0; r < E; ++r) buf[j + 64 * r] = v[r];
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < E; ++r) {
         const int k = j + 64 * r;
-        const float2 zk = v[r], zp = buf[(256 - k) & 255];
-        const float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));      // (Z[k] + conj Z[256-k]) / 2
-        const float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));      // (Z[k] - conj Z[256-k]) / 2
+        const float2 zk = v[r], zp = buf[(M - k) & (M - 1)];
+        const float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));      // (Z[k] + conj Z[M-k]) / 2
+        const float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));      // (Z[k] - conj Z[M-k]) / 2
         const float2 t = cmul(tw[k], d);                                               // w^k d
         dst[k] = make_float2(e.x + t.y, e.y - t.x);                                    // e - i t
-        if (k == 0) dst[256] = make_float2(zk.x - zk.y, 0.0f);
+        if (k == 0) dst[M] = make_float2(zk.x - zk.y, 0.0f);
+    }
+}
+
+__device__ __forceinline__ void wave_r2c_split512(const float2 *v, float2 *buf, const float2 *tw, int j, float2 *__restrict__ dst)
+{
+    wave_r2c_split<4>(v, buf, tw, j, dst);
+}
+
+// The inverse of wave_r2c_split: the lanes hold x[r] = X[j + 64 r] and xm = X[M] (lane 0) of a half
+// spectrum; returns Z with z = the unnormalised inverse M-point FFT still to be taken:
+//   Z[k] = (X[k] + conj X[M-k]) + i w^-k (X[k] - conj X[M-k]).   `buf` holds M + 1 elements.
+template <int E>
+__device__ __forceinline__ void wave_c2r_merge(const float2 *x, float2 xm, float2 *v, float2 *buf, const float2 *tw, int j)
+{
+    PM_FFT_FUSE
+    constexpr int M = 64 * E;
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < E; ++r) buf[j + 64 * r] = x[r];
+    if (j == 0) buf[M] = xm;
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int k = j + 64 * r;
+        float2 xk = x[r], xp = buf[M - k];
+        if (k == 0) { xk.y = 0.0f; xp.y = 0.0f; }                      // X[0] and X[M] of a real row are real
+        const float2 e = make_float2(xk.x + xp.x, xk.y - xp.y);        // X[k] + conj X[M-k]
+        const float2 d = make_float2(xk.x - xp.x, xk.y + xp.y);        // X[k] - conj X[M-k]
+        const float2 wk = tw[k];
+        const float2 t = cmul(make_float2(wk.x, -wk.y), d);            // w^-k d
+        v[r] = make_float2(e.x - t.y, e.y + t.x);                      // e + i t
     }
 }
 

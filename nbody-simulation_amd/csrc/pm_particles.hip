@@ -410,36 +410,37 @@ __device__ __forceinline__ void deposit_chunks(const pm_frac *__restrict__ F, co
     }
 }
 
-// A summed row leaves the kernel either as G float32 densities (SPECTRUM = false) or, for G = 512,
-// already transformed along z: the wave packs the row into 256 complex numbers, runs the 256-point
-// FFT and writes the 257 values of the row's half spectrum (SPECTRUM = true).  The density mesh is
-// then never written or read; the bits are those of writing it and transforming it afterwards.
-template <bool SPECTRUM>
+// A summed row leaves the kernel either as G float32 densities (NFFT = 0) or, for G = NFFT = 512 or
+// 1024, already transformed along z: the wave packs the row into NFFT/2 complex numbers, runs the FFT
+// and writes the NFFT/2 + 1 values of the row's half spectrum.  The density mesh is then never written
+// or read; the bits are those of writing it and transforming it afterwards.
+template <int NFFT>
 __device__ __forceinline__ void emit_row(double *acc, const float2 *tw, float *__restrict__ density, float2 *__restrict__ spectrum,
                                          uint32_t row, int G, int pitch)
 {
     const int j = lane_id();
-    if constexpr (SPECTRUM) {
-        float2 v[4];
+    if constexpr (NFFT != 0) {
+        constexpr int E = NFFT / 128;
+        float2 v[E];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < E; ++r) {
             const int n = j + 64 * r;
             v[r] = make_float2((float)acc[2 * n], (float)acc[2 * n + 1]);
         }
         float2 *buf = (float2 *)acc;                    // the row's LDS is free once every lane holds its part
-        pmfft::wave_fft256<-1>(v, buf, tw, j);
-        pmfft::wave_r2c_split512(v, buf, tw, j, spectrum + (size_t)row * pitch);
+        pmfft::wave_fft<E, -1>(v, buf, tw, j);
+        pmfft::wave_r2c_split<E>(v, buf, tw, j, spectrum + (size_t)row * pitch);
     } else {
         float *out = density + (size_t)row * G;
         for (int c = j; c < G; c += 64) out[c] = (float)acc[c];
     }
 }
 
-template <bool SPECTRUM>
+template <int NFFT>
 __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, float2 *__restrict__ spectrum, uint32_t row, int G, int pitch)
 {
     const int j = lane_id();
-    if constexpr (SPECTRUM) {
+    if constexpr (NFFT != 0) {
         float2 *dst = spectrum + (size_t)row * pitch;
         for (int c = j; c <= G / 2; c += 64) dst[c] = make_float2(0.0f, 0.0f);
     } else {
@@ -451,27 +452,27 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
 // One wave per density row; rows cut into units are only listed: entry = (row, index of its first
 // unit).  One 64-bit counter hands out the list slot (high word) and the unit index (low word)
 // together, so the entries are in the order of their unit indices.
-template <bool SPECTRUM>
+template <int NFFT>
 __global__ void __launch_bounds__(BLOCK)
 k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
                const uint32_t *__restrict__ rs, float *__restrict__ density,
                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
                uint2 *__restrict__ heavy_rows, unsigned long long *__restrict__ heavy_count, pm_geom g)
 {
-    extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then 512 twiddles if SPECTRUM
+    extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then the NFFT twiddles
     const int G = g.G;
     const uint32_t R = (uint32_t)g.Gd * (uint32_t)G;
     const uint32_t row = blockIdx.x * (BLOCK / 64) + (uint32_t)wave_id();
     float2 *tw = (float2 *)(lds_rows + (size_t)(BLOCK / 64) * G);
-    if constexpr (SPECTRUM) {
-        for (int q = threadIdx.x; q < 512; q += BLOCK) tw[q] = twiddle[q];
+    if constexpr (NFFT != 0) {
+        for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
         __syncthreads();                                // the only block-wide barrier: before any wave leaves
     }
     if (row >= R) return;
     double *acc = lds_rows + (size_t)wave_id() * G;
     const row_runs t = runs_of(rs, row, g);
     if (t.longest == 0) {
-        emit_empty_row<SPECTRUM>(density, spectrum, row, G, g.Ghp);
+        emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp);
         return;
     }
     const packed_runs p(t);
@@ -493,7 +494,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         for (int q = 0; q < 4; ++q) deposit_chunks(F, key, t.beg[q], t.end[q], t.key0[q], q & 1, q & 2, G, acc);
     }
     pmfft::wave_sync();
-    emit_row<SPECTRUM>(acc, tw, density, spectrum, row, G, g.Ghp);
+    emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp);
 }
 
 // One wave per unit: particles [u * UNIT, (u + 1) * UNIT) of a listed row's packed sequence, summed
@@ -536,17 +537,17 @@ k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
 
 // One block per listed row: its units' rows added in unit order (a thread per column, four loads in
 // flight), then emitted like any other row.
-template <bool SPECTRUM>
+template <int NFFT>
 __global__ void __launch_bounds__(BLOCK)
 k_sum_units(const uint32_t *__restrict__ rs, const uint2 *__restrict__ heavy_rows, const unsigned long long *__restrict__ heavy_count,
             const double *__restrict__ partial, float *__restrict__ density, float2 *__restrict__ spectrum,
             const float2 *__restrict__ twiddle, pm_geom g)
 {
-    extern __shared__ double lds_rows[];                // one row of G doubles, then 512 twiddles if SPECTRUM
+    extern __shared__ double lds_rows[];                // one row of G doubles, then the NFFT twiddles
     const int G = g.G;
     float2 *tw = (float2 *)(lds_rows + G);
-    if constexpr (SPECTRUM) {
-        for (int q = threadIdx.x; q < 512; q += BLOCK) tw[q] = twiddle[q];
+    if constexpr (NFFT != 0) {
+        for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
     }
     const uint32_t entries = (uint32_t)(*heavy_count >> 32);
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
@@ -565,7 +566,7 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint2 *__restrict__ heavy_row
             lds_rows[c] = sum;
         }
         __syncthreads();
-        if (threadIdx.x < 64) emit_row<SPECTRUM>(lds_rows, tw, density, spectrum, entry.x, G, g.Ghp);
+        if (threadIdx.x < 64) emit_row<NFFT>(lds_rows, tw, density, spectrum, entry.x, G, g.Ghp);
         __syncthreads();
     }
 }
@@ -858,27 +859,29 @@ size_t pm_heavy_row_entries(int G, int64_t cap)
 // Units: one per UNIT particles of a listed row, plus at most one partly filled unit per row.
 size_t pm_unit_rows(int G, int64_t cap) { return (size_t)(4 * cap / UNIT) + pm_heavy_row_entries(G, cap); }
 
-template <bool SPECTRUM>
+template <int NFFT>
 static hipError_t deposit_dispatch(pm_ctx *c)
 {
     const int G = c->g.G;
     const uint32_t R = (uint32_t)c->g.Gd * (uint32_t)G;
     hipError_t e = hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream);
     if (e != hipSuccess) return e;
-    const size_t tw_bytes = SPECTRUM ? 512 * sizeof(float2) : 0;
+    const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
-    k_deposit_rows<SPECTRUM><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
+    k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
         c->frac, c->key_out, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
     k_deposit_units<<<PM_UNIT_GRID, BLOCK, lds_rows, c->stream>>>(c->frac, c->key_out, c->row_start, c->heavy_rows, c->counters, c->unit_rows, c->g);
-    k_sum_units<SPECTRUM><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->heavy_rows, c->counters, c->unit_rows, c->density,
+    k_sum_units<NFFT><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->heavy_rows, c->counters, c->unit_rows, c->density,
                                                                         c->spectrum, c->twiddle, c->g);
     return hipGetLastError();
 }
 
-// to_spectrum: leave the z-transformed rows in the half spectrum instead of the density mesh (G = 512 only)
+// to_spectrum: leave the z-transformed rows in the half spectrum instead of the density mesh (grid sizes of the
+// hand-written transforms only)
 hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum)
 {
-    return to_spectrum ? deposit_dispatch<true>(c) : deposit_dispatch<false>(c);
+    if (!to_spectrum) return deposit_dispatch<0>(c);
+    return c->g.G == 512 ? deposit_dispatch<512>(c) : deposit_dispatch<1024>(c);
 }
 
 template <typename TP, typename TV>

@@ -152,7 +152,7 @@ def test_fused_step_512(pm):
     dx = np.abs(out[0][0].astype(np.float64) - out[1][0])
     assert np.minimum(dx, L - dx).max() <= 1e-6 * L
     assert np.abs(out[0][1] - out[1][1]).max() <= 1e-6 * np.abs(out[0][1]).max()
-    print("fused == staged bitwise:", np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])     # the same bits, in fact
 
 
 def test_cell_order_over_steps(pm, golden):
@@ -303,6 +303,56 @@ def test_poisson_512_column_fft(pm):
             f = min(m, G - m) / G
             want = mode / np.float32(f * f)
             assert np.abs(sim.potential() - want).max() <= 2e-5 * np.abs(want).max(), (ax, m)
+
+
+def test_poisson_1024_column_fft(pm):
+    """G = 1024 (radix 16, 8, 8 columns; 512-point rows): against the rocFFT-only path, which the small-mesh tests pin
+    to the oracle, and on single Fourier modes with their analytic answer."""
+    G = 1024
+    rng = np.random.default_rng(4)
+    dens = rng.random((G, G, G), dtype=np.float32)
+    dens[100:110, 900:910, 300:310] += 50.0
+    pots = []
+    for rocfft_only in (False, True):
+        with pm.Simulation(G, 1.0, capacity=1, rocfft_only=rocfft_only) as sim:
+            sim.set_mesh(0, dens)
+            sim.solve_potential()
+            pots.append(sim.potential())
+    scale = np.abs(pots[1]).max()
+    assert np.abs(pots[0] - pots[1]).max() <= 1e-5 * scale
+    del pots, dens
+    i = np.arange(G)
+    with pm.Simulation(G, 1.0, capacity=1) as sim:
+        for ax, m in ((0, 3), (1, 700), (2, 512), (0, 1023), (2, 37)):
+            shape = [1, 1, 1]
+            shape[ax] = G
+            mode = np.broadcast_to(np.cos(2 * np.pi * m * i / G).reshape(shape), (G, G, G)).astype(np.float32)
+            sim.set_mesh(0, mode)
+            sim.solve_potential()
+            f = min(m, G - m) / G
+            want = mode / np.float32(f * f)
+            assert np.abs(sim.potential() - want).max() <= 2e-5 * np.abs(want).max(), (ax, m)
+
+
+def test_fused_step_1024(pm):
+    """G = 1024: the fused step against the stage-by-stage step and against the rocFFT-only pipeline."""
+    n, G, L, dt = 400_000, 1024, 10000, 0.005
+    rng = np.random.default_rng(9)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    pos[: n // 2] = (5000 + rng.normal(0, 40, (n // 2, 3))).astype(np.float32)
+    vel = rng.normal(0, 2000, (n, 3)).astype(np.float32)
+    mass = (rng.random(n) + 0.5).astype(np.float32) * 100
+    out = []
+    for fused, rocfft_only in ((False, False), (True, False), (False, True)):
+        with pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused, rocfft_only=rocfft_only) as sim:
+            sim.step(dt, 2)
+            out.append((sim.positions(), sim.velocities()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # two float32 implementations of a 1024^3 transform agree to ~1e-6 of max|phi|; the difference quotient of the
+    # gradient and the dense clump's large forces carry that into the velocities at a few 1e-5 of max|v|
+    dx = np.abs(out[0][0].astype(np.float64) - out[2][0])
+    assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+    assert np.abs(out[0][1] - out[2][1]).max() <= 5e-5 * np.abs(out[2][1]).max()
 
 
 def test_clustered_hot_cell(pm):
