@@ -246,11 +246,12 @@ k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, con
 template <int N, int DIR, bool GREEN>
 hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
 {
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[64] = {};                       // the attribute is per device
+    const int dev = c->device & 63;
+    if (!attr[dev]) {
         hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N>::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr[dev] = true;
     }
     k_col_fft<N, DIR, GREEN><<<blocks, col_plan<N>::THREADS, col_plan<N>::LDS_BYTES, c->stream>>>(p, c->twiddle);
     return hipGetLastError();
