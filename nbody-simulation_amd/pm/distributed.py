@@ -169,6 +169,18 @@ class _Comm:
             dist.all_to_all_single(recv, send, [int(x) for x in recv_sizes], [c.numel() for c in chunks], group=self.group)
         return list(torch.split(recv, [int(x) for x in recv_sizes]))
 
+    def all_to_all_equal(self, send, recv):
+        """The same with one contiguous buffer each way and equal shares: rank p's share of `send` lands in share
+        `rank-of-sender` of `recv`.  No copies besides the exchange itself."""
+        if self.world == 1:
+            recv.copy_(send)
+        elif self.stage_on_host and send.is_cuda:
+            s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(r, s, group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+
     def barrier(self):
         if self.on:
             dist.barrier(group=self.group)
@@ -234,13 +246,10 @@ class SlabSimulation:
         # compute_potential (functions.py:73-89)
         e.fft2(-1)
         blocks = e.pack()
-        per_peer = blocks.numel() // world
-        got = self.comm.all_to_all(list(torch.split(blocks.reshape(-1), per_peer)), [per_peer] * world)
         spec_t = e.transposed_buffer()
-        torch.cat(got, out=spec_t.reshape(-1))
+        self.comm.all_to_all_equal(blocks.reshape(-1), spec_t.reshape(-1))
         e.solve_x(spec_t)
-        got = self.comm.all_to_all(list(torch.split(spec_t.reshape(-1), per_peer)), [per_peer] * world)
-        torch.cat(got, out=blocks.reshape(-1))
+        self.comm.all_to_all_equal(spec_t.reshape(-1), blocks.reshape(-1))
         e.unpack(blocks)
         e.fft2(+1)
         # potential planes beside the slab: one below (from the previous rank), two above (from the next rank)

@@ -367,6 +367,21 @@ def test_clustered_hot_cell(pm):
         assert_density(sim.density(), O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
 
 
+@pytest.mark.parametrize("G,n", [(32, 150_000), (16, 200_000), (8, 300_000), (6, 70_001)])
+def test_deposit_walks(pm, G, n):
+    """The three walks of the deposit -- one particle per lane (few particles per row), four per lane (hundreds to
+    thousands), rows cut into units (more) -- on meshes small enough that every row, including the wrapped ones at
+    i = 0 and j = 0, takes the walk in question; uneven masses, runs that start at any alignment."""
+    L = 1000
+    rng = np.random.default_rng(G)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    pos[: n // 3, 2] = (rng.random(n // 3) * (L / G) + 3 * (L / G)).astype(np.float32)     # a third of them in the cells k = 3
+    mass = (rng.random(n) * 2 + 0.01).astype(np.float32)
+    with pm.Simulation(G, L, pos, None, mass) as sim:
+        sim.deposit()
+        assert_density(sim.density(), O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
+
+
 def test_deposit_is_bitwise_reproducible(pm):
     """Same input, fresh engines, clustered and sparse rows alike: identical bits every time."""
     n, G, L = 300_000, 64, 10000
