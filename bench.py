@@ -100,8 +100,8 @@ def stage_bytes(n, m, fused=False):
 # kernels that make up each timed stage (substrings of the names rocprofv3 reports)
 STAGE_KERNELS = {"bin": ["rocprim", "k_reorder", "k_row_start", "k_cell_keys"],
                  "deposit": ["k_deposit_rows", "k_deposit_units", "k_sum_units"],
-                 "fft_fwd": ["k_row_r2c512", "k_col_fft512<-1, false>"], "green": ["k_col_fft512<-1, true>", "k_green"],
-                 "fft_inv": ["k_col_fft512<1, false>", "k_row_c2r512"], "gradient": ["k_gradient"], "gather": ["k_gather"]}
+                 "fft_fwd": ["k_row_r2c", "k_col_fft<512, -1, false>"], "green": ["k_col_fft<512, -1, true>", "k_green"],
+                 "fft_inv": ["k_col_fft<512, 1, false>", "k_row_c2r"], "gradient": ["k_gradient"], "gather": ["k_gather"]}
 
 
 def measured_traffic(stage):
