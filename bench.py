@@ -86,15 +86,24 @@ def make_workload(name, n, L, seed):
 
 
 def stage_bytes(n, m, fused=False):
-    """Algorithmic bytes of each timed stage; they add up to 64 N + 80 M.  Staged: deposit, three forward
-    axis passes, Green multiply (no traffic of its own), three inverse passes, gradient, gather.  Fused
-    (G = 512): the deposit kernel also does the forward z pass, the `green` kernel is the forward and
-    inverse x passes around the multiply, and the gather also differences the potential."""
+    """Algorithmic bytes of each timed stage as the per-stage figures that add up to 64 N + 80 M: deposit 16N + 4M,
+    three forward axis passes 24M, Green multiply 0, three inverse passes 24M, gradient 16M, gather 48N + 12M.  In the
+    fused pipeline (G = 512 / 1024) a timed stage covers more than one of these: the deposit kernels also do the forward
+    z pass, `green` is the forward and inverse x passes around the multiply, the gather also differences the potential."""
     if fused:
         return {"bin": 0, "deposit": 16 * n + 4 * m + 8 * m, "fft_fwd": 8 * m, "green": 16 * m, "fft_inv": 16 * m,
                 "gradient": 0, "gather": 48 * n + 12 * m + 16 * m}
     return {"bin": 0, "deposit": 16 * n + 4 * m, "fft_fwd": 24 * m, "green": 0, "fft_inv": 24 * m,
             "gradient": 16 * m, "gather": 48 * n + 12 * m}
+
+
+def kernel_bytes(n, m):
+    """Stages of the fused pipeline that are ONE kernel launch, with the bytes that launch cannot avoid moving: a
+    column pass reads and writes the half spectrum once (8M, also when it transforms forward and back in one go), the
+    gather reads and writes position and velocity (48N) and reads the potential once (4M; the three gradient meshes
+    of the staged pipeline, 12M there, do not exist here)."""
+    return {"fft_fwd": ("k_col_fft<512, -1, false>", 8 * m), "green": ("k_col_fft<512, -1, true>", 8 * m),
+            "gather": ("k_gather", 48 * n + 4 * m)}
 
 
 # kernels that make up each timed stage (substrings of the names rocprofv3 reports)
@@ -205,8 +214,15 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         b = stage_bytes(n, m, fused and G == 512)
         per = {s: (ms / c if c else 0.0) for s, (ms, c) in stages.items()}
-        dom = max((s for s in per if b[s] > 0), key=lambda s: per[s])
-        ach = b[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+        if fused and G == 512:
+            # the dominant kernel: the longest-running stage that is a single launch, priced with what it must move
+            kb = kernel_bytes(n, m)
+            dom = max(kb, key=lambda s: per[s])
+            dom_name, dom_bytes = kb[dom]
+        else:
+            dom = max((s for s in per if b[s] > 0), key=lambda s: per[s])
+            dom_name, dom_bytes = dom, b[dom]
+        ach = dom_bytes / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
         b_step = 64 * n + 80 * m
         out = {
             "metric": "particle-updates/sec per PM step (N=16M, 512^3 mesh)",
@@ -216,10 +232,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "fused_gradient": fused,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom_name, "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS,
                          "traffic": measured_traffic(dom) if (args.workload == "two_galaxy" and n == 16_777_216 and G == 512) else None,
-                         "algorithmic_bytes_per_launch": b[dom], "ms_per_launch": per[dom]},
+                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": per[dom]},
             "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved": b_step / (ms_step * 1e-3) / 1e9,
                               "unit": "GB/s", "frac": b_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "stage_ms": per,
