@@ -42,6 +42,8 @@ struct col_pass {
     int G;
     float invM;
     int outer0;             // mesh index of outer index 0 (Green multiply)
+    int tile0;              // first column tile of this launch (a launch may cover a range of tiles only)
+    int ntiles;             // column tiles per outer index in this launch
 };
 
 // Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 8 at N = 512, 16 at N = 1024).  A column is
@@ -69,7 +71,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
     float2 *tile = lds;
     float2 *tw = lds + N * COLS;
     const int t = threadIdx.x, c = t & (COLS - 1), jl = t >> 4;
-    const int outer = blockIdx.x / p.tiles, ct = blockIdx.x % p.tiles;
+    const int outer = blockIdx.x / p.ntiles, ct = p.tile0 + blockIdx.x % p.ntiles;
     const int col = ct * COLS + c;
     const bool valid = col < p.ncols;
     float2 *g = p.spec + (int64_t)outer * p.outer_stride + col;
@@ -228,7 +230,8 @@ k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, con
     float2 *buf = bufs[w];
     for (int q = threadIdx.x; q < N; q += FFT_BLOCK) tw[q] = twiddle[q];
     __syncthreads();
-    const int64_t row0 = ((int64_t)blockIdx.x * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
+    // last planes first: the pass along y before this one ends with them, and the gather after it starts with the first
+    const int64_t row0 = ((int64_t)(gridDim.x - 1 - blockIdx.x) * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
         const float2 *src = in + (row0 + rr) * pitch;
         float2 x[E], v[E];
@@ -315,7 +318,7 @@ static col_pass pass_for(pm_ctx *c, float2 *spec)
 {
     const int G = c->g.G, P = c->g.Ghp;
     col_pass p{};
-    p.spec = spec; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS;
+    p.spec = spec; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS; p.tile0 = 0; p.ntiles = p.tiles;
     p.invM = (float)(1.0 / (double)c->g.M);
     return p;
 }
@@ -329,6 +332,19 @@ hipError_t pm_launch_col_fft(pm_ctx *c, int dir)
     else { p.outer_stride = (int64_t)G * P; p.row_stride = P; }
     return launch_col_any(c, dir, p, G * p.tiles);
 }
+
+// The same on column tiles [tile0, tile0 + ntiles) only (a tile is 16 neighbouring columns c of all rows).
+hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles)
+{
+    const int G = c->g.G, P = c->g.Ghp;
+    col_pass p = pass_for(c, c->spectrum);
+    if (dir == 0) { p.outer_stride = P; p.row_stride = (int64_t)G * P; }
+    else { p.outer_stride = (int64_t)G * P; p.row_stride = P; }
+    p.tile0 = tile0; p.ntiles = ntiles;
+    return launch_col_any(c, dir, p, G * ntiles);
+}
+
+int pm_fft_tiles(const pm_ctx *c) { return c->g.Ghp / COLS; }
 
 // ---- the same passes on some planes of the mesh (slab decomposition) ------------------------------
 

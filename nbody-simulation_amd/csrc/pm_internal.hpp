@@ -151,6 +151,8 @@ hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count);
 hipError_t pm_launch_set_ids(pm_ctx *c, const uint32_t *ids);
 hipError_t pm_launch_export_slab(pm_ctx *c, uint32_t *ids, float *pos, float *vel);
 hipError_t pm_launch_row_fft(pm_ctx *c, bool forward);
+hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles);
+int pm_fft_tiles(const pm_ctx *c);
 hipError_t pm_launch_gradient(pm_ctx *c);
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);
 hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos);

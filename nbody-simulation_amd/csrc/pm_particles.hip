@@ -462,7 +462,9 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then the NFFT twiddles
     const int G = g.G;
     const uint32_t R = (uint32_t)g.Gd * (uint32_t)G;
-    const uint32_t row = blockIdx.x * (BLOCK / 64) + (uint32_t)wave_id();
+    // last rows first: the reorder pass has just written the records of the last rows, and the transform along y that
+    // follows starts with the first planes -- each kernel meets the other's most recent output while caches still hold it
+    const uint32_t row = (gridDim.x - 1 - blockIdx.x) * (BLOCK / 64) + (uint32_t)wave_id();
     float2 *tw = (float2 *)(lds_rows + (size_t)(BLOCK / 64) * G);
     if constexpr (NFFT != 0) {
         for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
