@@ -143,7 +143,9 @@ class HipSlabEngine:
 class _Comm:
     """all-to-all of flat float32 / int64 tensors; the only collective the step needs."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_collective=False):
+        # always_collective: go through torch.distributed even when this is the only rank (tests of the backend)
+        self.always = always_collective
         self.on = dist.is_available() and dist.is_initialized()
         self.group = group
         self.rank = dist.get_rank(group) if self.on else 0
@@ -154,7 +156,7 @@ class _Comm:
     def all_to_all(self, chunks, recv_sizes):
         """chunks[p]: 1-D tensor for rank p; recv_sizes[p]: elements expected from rank p.  Returns the list received."""
         dtype, device = chunks[0].dtype, chunks[0].device
-        if self.world == 1:
+        if self.world == 1 and not (self.always and self.on):
             return [chunks[0].clone()]
         send = torch.cat([c.reshape(-1) for c in chunks])
         if self.backend == "nccl" and not send.is_cuda:     # RCCL moves device memory only (the particle counts are host integers)
@@ -172,7 +174,7 @@ class _Comm:
     def all_to_all_equal(self, send, recv):
         """The same with one contiguous buffer each way and equal shares: rank p's share of `send` lands in share
         `rank-of-sender` of `recv`.  No copies besides the exchange itself."""
-        if self.world == 1:
+        if self.world == 1 and not (self.always and self.on):
             recv.copy_(send)
         elif self.stage_on_host and send.is_cuda:
             s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
@@ -191,8 +193,8 @@ class SlabSimulation:
     numbers in the whole run; `engine` defaults to HipSlabEngine on cuda:`device_index`."""
 
     def __init__(self, grid_size, box_size, positions, velocities, masses, ids, *, group=None, device_index=0, engine=None,
-                 capacity=None):
-        self.comm = _Comm(group)
+                 capacity=None, always_collective=False):
+        self.comm = _Comm(group, always_collective)
         self.G, self.L = int(grid_size), float(box_size)
         world, rank = self.comm.world, self.comm.rank
         if self.G % world:

@@ -100,6 +100,38 @@ def test_slab_world2_one_gpu(case, tmp_path):
     assert check(case, outs) > 50
 
 
+def _rccl_single_rank(port, out):
+    import torch
+    import torch.distributed as dist
+    from pm.distributed import SlabSimulation
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    c = CASES["g32"]
+    pos, vel, mass = make(c["n"], c["L"], 3, c["crowd"])
+    ids = np.arange(c["n"], dtype=np.uint32)
+    with SlabSimulation(c["G"], c["L"], pos, vel, mass, ids, device_index=0, capacity=c["n"], always_collective=True) as sim:
+        sim.step(c["dt"], c["K"])
+        i, x, v = sim.particles()
+    np.savez(out, ids=i, pos=x, vel=v, moved=0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_collectives_over_rccl_single_rank(tmp_path):
+    """Every exchange of the step as a real RCCL collective (backend "nccl"), on the one rank a one-GPU box can hold:
+    device tensors, the host-side particle counts, empty shares.  More ranks need more GPUs."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "r0.npz")
+    p = mp.get_context("spawn").Process(target=_rccl_single_rank, args=(port, out))
+    p.start()
+    p.join(200)
+    assert p.exitcode == 0
+    check("g32", [out])
+
+
 def test_slab_matches_oracle_world1(tmp_path):
     """The same g32 run against the CPU oracle."""
     from oracle import pm_oracle as O
