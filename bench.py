@@ -152,10 +152,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="two_galaxy", choices=["two_galaxy", "uniform", "disk"])
-    ap.add_argument("--n", type=int, default=16_777_216)
+    ap.add_argument("--n", "--particles", dest="n", type=int, default=16_777_216)
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--no-fused-gradient", action="store_true")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    ap.add_argument("--no-slab-probe", action="store_true",
+                    help="--gpus N > 1 in replica mode: do not also run the slab-decomposed step in child processes")
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
                     help="--gpus N > 1: N independent replicas of the workload (default), or ONE run of the workload with the "
                          "mesh cut into N slabs (all-to-all transposes, halo planes and particle migration over RCCL)")
@@ -164,6 +166,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch                              # (counting devices does not touch the GPU)
+        local_rank %= max(1, torch.cuda.device_count())       # more ranks than GPUs: rehearsals on a one-GPU box
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run for --gpus > 1")
@@ -210,6 +215,11 @@ def main():
     stages = sim.stage_times()
     sim.set_flags(timing=False, fused_gradient=fused)
 
+    sim.close()
+    slab = None
+    if world > 1 and not args.no_slab_probe:
+        slab = slab_probe(args, rank, world, dist)
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         b = stage_bytes(n, m, fused and G == 512)
@@ -242,11 +252,41 @@ def main():
         }
         if args.cpu_baseline == "auto" and world == 1:
             out["cpu_baseline"] = cpu_baseline(pos, vel, mass, G, L, DT)
+        if slab is not None:
+            out["slab_decomposed"] = slab
         print(json.dumps(out), flush=True)
-    sim.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def slab_probe(args, rank, world, dist):
+    """The same workload as ONE simulation over `world` slabs (bench.py --parallelism slab), run by a child process
+    per rank with its own rendezvous, so that whatever happens to it -- RCCL has only ever run with one rank where this
+    was developed -- the replica measurement above stands.  Returns what rank 0's child printed, or what went wrong."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 29)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 10)), "--warmup", "2",
+           "--parallelism", "slab", "--workload", args.workload, "--particles", str(args.n), "--grid", str(args.grid)]
+    dist.barrier()
+    if rank == 0:
+        print("bench: replica measurement done; probing the slab-decomposed step in child processes (at most 100 s)", file=sys.stderr, flush=True)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and (lines or rank != 0):
+            res = json.loads(lines[-1]) if lines else None
+            if res is not None:
+                res = {k: res[k] for k in ("value", "unit", "ms_per_step", "scaling", "config")}
+        else:
+            res = {"error": f"exit code {r.returncode}: " + r.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        res = {"error": "no result within 100 s"}
+    except Exception as e:                           # the probe must not take the measurement down with it
+        res = {"error": repr(e)}
+    dist.barrier()
+    return res
 
 
 def slab_main(args, rank, world, local_rank):
