@@ -104,6 +104,13 @@ int ensure_binned(pm_ctx *c)
     return PM_OK;
 }
 
+int whole_mesh(pm_ctx *c)
+{
+    if (!c) return PM_EINVAL;
+    if (c->slab) return fail(c, PM_ESTATE, "this call works on the whole mesh: a slab context takes the pm_slab_* calls");
+    return PM_OK;
+}
+
 int need_particles(pm_ctx *c)
 {
     if (!c) return PM_EINVAL;
@@ -112,6 +119,94 @@ int need_particles(pm_ctx *c)
 }
 
 }  // namespace
+
+static int create_impl(pm_ctx *c)
+{
+    const int G = c->g.G;
+    const size_t M = (size_t)c->g.M, cap = (size_t)c->cap;
+    const size_t plane = (size_t)G * G, planes = (size_t)c->g.Gs;    // a slab context holds its own planes only
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int s = 0; s < PM_NSTAGES; ++s)
+        for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
+
+    // the deposit reads keys and fraction records in groups of four: three entries of slack
+    TRY(dalloc(c, &c->frac, cap + 4));
+    TRY(dalloc(c, &c->key_in, cap + 4));
+    TRY(dalloc(c, &c->key_out, cap + 4));
+    TRY(dalloc(c, &c->src, cap));
+    c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
+    HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
+    TRY(dalloc(c, &c->row_start, planes * G + 1));
+    TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G, cap)));
+    TRY(dalloc(c, &c->counters, 1));
+    TRY(dalloc(c, &c->unit_rows, pm_unit_rows(G, cap) * (size_t)G));
+    // a slab context keeps one more density plane and three more potential planes than it owns, and no gradient meshes
+    TRY(dalloc(c, &c->density, (planes + 1) * plane));
+    TRY(dalloc(c, &c->potential, (planes + 3) * plane));
+    if (!c->slab)
+        for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
+    TRY(dalloc(c, &c->spectrum, planes * G * c->g.Ghp));
+    TRY(dalloc(c, &c->forces, 3 * cap));
+    TRY(dalloc(c, &c->diag, 2 * 1024 + 4));
+    HIP_TRY(c, hipMalloc(&c->stage, cap * 32 + 16));
+
+    std::call_once(g_fft_once, [] { rocfft_setup(); });
+    if (c->fft_custom) {
+        HIP_TRY(c, pm_fft_upload_twiddles(c));
+        return PM_OK;
+    } else if (c->slab) {
+        FFT_TRY(c, rocfft_execution_info_create(&c->info));      // the slab's own plans are made by pm_create_slab
+        FFT_TRY(c, rocfft_execution_info_set_stream(c->info, c->stream));
+        return PM_OK;
+    } else {
+        const size_t lengths[3] = {(size_t)G, (size_t)G, (size_t)G};
+        FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                      rocfft_precision_single, 3, lengths, 1, nullptr));
+        FFT_TRY(c, rocfft_plan_create(&c->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                      rocfft_precision_single, 3, lengths, 1, nullptr));
+    }
+    size_t wf = 0, wi = 0;
+    FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->fwd, &wf));
+    FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->inv, &wi));
+    c->fft_work_bytes = wf > wi ? wf : wi;
+    FFT_TRY(c, rocfft_execution_info_create(&c->info));
+    if (c->fft_work_bytes) {
+        HIP_TRY(c, hipMalloc(&c->fft_work, c->fft_work_bytes));
+        FFT_TRY(c, rocfft_execution_info_set_work_buffer(c->info, c->fft_work, c->fft_work_bytes));
+    }
+    FFT_TRY(c, rocfft_execution_info_set_stream(c->info, c->stream));
+    return PM_OK;
+}
+
+// A context for planes [plane0, plane0 + nplanes) of the mesh: all of them (pm_create) or a slab (pm_create_slab).
+pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab)
+{
+    if (grid_size < 2 || grid_size > 1625) { fail(nullptr, PM_EINVAL, "grid_size must be in [2, 1625] (cell keys are 32-bit)"); return nullptr; }
+    if (!(box_size > 0.0) || !std::isfinite(box_size)) { fail(nullptr, PM_EINVAL, "box_size must be positive and finite"); return nullptr; }
+    if (n_capacity < 0 || n_capacity >= ((int64_t)1 << 31)) { fail(nullptr, PM_EINVAL, "n_capacity must be in [0, 2^31-1]"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        fail(nullptr, PM_EHIP, "no such HIP device: " + std::to_string(device) + " of " + std::to_string(ndev));
+        return nullptr;
+    }
+    pm_ctx *c = new pm_ctx;
+    c->g.G = grid_size; c->g.Gh = grid_size / 2 + 1;
+    c->fft_custom = pm_fft_custom_supported(grid_size) && !(flags & PM_FLAG_ROCFFT_ONLY);
+    c->g.Ghp = c->fft_custom ? pm_fft_pitch(grid_size) : c->g.Gh;
+    c->g.M = (int64_t)grid_size * grid_size * grid_size;
+    c->g.L = box_size; c->g.inv = (double)grid_size / box_size; c->g.Lf = (float)box_size;
+    c->slab = slab;
+    c->nslabs = grid_size / nplanes;
+    c->g.i0 = plane0; c->g.Gs = nplanes; c->g.Gd = slab ? nplanes + 1 : grid_size; c->g.lo = slab ? 1 : 0;
+    c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
+    if (create_impl(c) != PM_OK) {
+        g_create_error = c->err;
+        pm_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
 
 extern "C" {
 
@@ -145,83 +240,9 @@ void pm_destroy(pm_ctx *c)
     delete c;
 }
 
-static int create_impl(pm_ctx *c)
-{
-    const int G = c->g.G;
-    const size_t M = (size_t)c->g.M, cap = (size_t)c->cap;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int s = 0; s < PM_NSTAGES; ++s)
-        for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
-
-    // the deposit reads keys and fraction records in groups of four: three entries of slack
-    TRY(dalloc(c, &c->frac, cap + 4));
-    TRY(dalloc(c, &c->key_in, cap + 4));
-    TRY(dalloc(c, &c->key_out, cap + 4));
-    TRY(dalloc(c, &c->src, cap));
-    c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
-    HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
-    TRY(dalloc(c, &c->row_start, (size_t)G * G + 1));
-    TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G, cap)));
-    TRY(dalloc(c, &c->counters, 1));
-    TRY(dalloc(c, &c->unit_rows, pm_unit_rows(G, cap) * (size_t)G));
-    // a slab context keeps one more density plane and three more potential planes than it owns
-    TRY(dalloc(c, &c->density, M + (size_t)G * G));
-    TRY(dalloc(c, &c->potential, M + 3 * (size_t)G * G));
-    for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
-    TRY(dalloc(c, &c->spectrum, (size_t)G * G * c->g.Ghp));
-    TRY(dalloc(c, &c->forces, 3 * cap));
-    TRY(dalloc(c, &c->diag, 2 * 1024 + 4));
-    HIP_TRY(c, hipMalloc(&c->stage, cap * 32 + 16));
-
-    std::call_once(g_fft_once, [] { rocfft_setup(); });
-    if (c->fft_custom) {
-        HIP_TRY(c, pm_fft_upload_twiddles(c));
-        return PM_OK;
-    } else {
-        const size_t lengths[3] = {(size_t)G, (size_t)G, (size_t)G};
-        FFT_TRY(c, rocfft_plan_create(&c->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                                      rocfft_precision_single, 3, lengths, 1, nullptr));
-        FFT_TRY(c, rocfft_plan_create(&c->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
-                                      rocfft_precision_single, 3, lengths, 1, nullptr));
-    }
-    size_t wf = 0, wi = 0;
-    FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->fwd, &wf));
-    FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->inv, &wi));
-    c->fft_work_bytes = wf > wi ? wf : wi;
-    FFT_TRY(c, rocfft_execution_info_create(&c->info));
-    if (c->fft_work_bytes) {
-        HIP_TRY(c, hipMalloc(&c->fft_work, c->fft_work_bytes));
-        FFT_TRY(c, rocfft_execution_info_set_work_buffer(c->info, c->fft_work, c->fft_work_bytes));
-    }
-    FFT_TRY(c, rocfft_execution_info_set_stream(c->info, c->stream));
-    return PM_OK;
-}
-
 pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags)
 {
-    if (grid_size < 2 || grid_size > 1625) { fail(nullptr, PM_EINVAL, "grid_size must be in [2, 1625] (cell keys are 32-bit)"); return nullptr; }
-    if (!(box_size > 0.0) || !std::isfinite(box_size)) { fail(nullptr, PM_EINVAL, "box_size must be positive and finite"); return nullptr; }
-    if (n_capacity < 0 || n_capacity >= ((int64_t)1 << 31)) { fail(nullptr, PM_EINVAL, "n_capacity must be in [0, 2^31-1]"); return nullptr; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
-        fail(nullptr, PM_EHIP, "no such HIP device: " + std::to_string(device) + " of " + std::to_string(ndev));
-        return nullptr;
-    }
-    pm_ctx *c = new pm_ctx;
-    c->g.G = grid_size; c->g.Gh = grid_size / 2 + 1;
-    c->fft_custom = pm_fft_custom_supported(grid_size) && !(flags & PM_FLAG_ROCFFT_ONLY);
-    c->g.Ghp = c->fft_custom ? pm_fft_pitch(grid_size) : c->g.Gh;
-    c->g.M = (int64_t)grid_size * grid_size * grid_size;
-    c->g.L = box_size; c->g.inv = (double)grid_size / box_size; c->g.Lf = (float)box_size;
-    c->g.i0 = 0; c->g.Gs = grid_size; c->g.Gd = grid_size; c->g.lo = 0;
-    c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
-    if (create_impl(c) != PM_OK) {
-        g_create_error = c->err;
-        pm_destroy(c);
-        return nullptr;
-    }
-    return c;
+    return pm_create_planes(grid_size, box_size, n_capacity, device, flags, 0, grid_size, false);
 }
 
 int pm_synchronize(pm_ctx *c)
@@ -263,6 +284,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
 
 static int deposit_impl(pm_ctx *c, bool to_spectrum)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(ensure_binned(c));
@@ -276,6 +298,7 @@ int pm_deposit(pm_ctx *c) { return deposit_impl(c, false); }
 // have_z: the half spectrum already holds the z-transformed density rows (fused deposit)
 static int potential_impl(pm_ctx *c, bool have_z)
 {
+    TRY(whole_mesh(c));
     if (!c) return PM_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->fft_custom && !(c->flags & PM_FLAG_TIMING)) {
@@ -330,6 +353,7 @@ int pm_potential(pm_ctx *c) { return potential_impl(c, false); }
 
 int pm_gradient(pm_ctx *c)
 {
+    TRY(whole_mesh(c));
     if (!c) return PM_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     stage_timer t(c, PM_STAGE_GRADIENT);
@@ -339,6 +363,7 @@ int pm_gradient(pm_ctx *c)
 
 int pm_forces(pm_ctx *c)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     HIP_TRY(c, hipSetDevice(c->device));
     stage_timer t(c, PM_STAGE_GATHER);
@@ -360,6 +385,7 @@ static int gather_kick_drift(pm_ctx *c, double dt, bool fused)
 
 int pm_gather_kick_drift(pm_ctx *c, double dt)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     HIP_TRY(c, hipSetDevice(c->device));
     return gather_kick_drift(c, dt, false);
@@ -367,6 +393,7 @@ int pm_gather_kick_drift(pm_ctx *c, double dt)
 
 int pm_step(pm_ctx *c, double dt, int nsteps)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     if (nsteps < 0) return fail(c, PM_EINVAL, "nsteps < 0");
     const bool fused = (c->flags & PM_FLAG_FUSED_GRADIENT) != 0;
@@ -383,6 +410,7 @@ int pm_step(pm_ctx *c, double dt, int nsteps)
 
 int pm_get_particles(pm_ctx *c, void *pos, int *pos_dtype, void *vel, int *vel_dtype)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = (size_t)c->n;
@@ -403,6 +431,7 @@ int pm_get_particles(pm_ctx *c, void *pos, int *pos_dtype, void *vel, int *vel_d
 
 int pm_get_forces(pm_ctx *c, float *forces)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     if (!c->have_forces) return fail(c, PM_ESTATE, "no forces: call pm_forces first");
     if (!forces) return fail(c, PM_EINVAL, "forces is NULL");
@@ -430,6 +459,7 @@ static float *mesh_ptr(pm_ctx *c, int which)
 int pm_get_mesh(pm_ctx *c, int which, float *out)
 {
     if (!c) return PM_EINVAL;
+    if (c->slab) return fail(c, PM_ESTATE, "a slab context has no whole meshes: use pm_slab_planes");
     float *p = mesh_ptr(c, which);
     if (!p || !out) return fail(c, PM_EINVAL, "bad mesh selector or NULL buffer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -441,6 +471,7 @@ int pm_get_mesh(pm_ctx *c, int which, float *out)
 int pm_set_mesh(pm_ctx *c, int which, const float *in)
 {
     if (!c) return PM_EINVAL;
+    if (c->slab) return fail(c, PM_ESTATE, "a slab context has no whole meshes: use pm_slab_planes");
     float *p = mesh_ptr(c, which);
     if (!p || !in) return fail(c, PM_EINVAL, "bad mesh selector or NULL buffer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -451,6 +482,7 @@ int pm_set_mesh(pm_ctx *c, int which, const float *in)
 
 int pm_get_cell_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     if (!keys || !perm) return fail(c, PM_EINVAL, "NULL buffer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -468,6 +500,7 @@ int pm_get_cell_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
 
 int pm_energies(pm_ctx *c, double *ke, double *pe)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     if (!ke || !pe) return fail(c, PM_EINVAL, "NULL buffer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -482,6 +515,7 @@ int pm_energies(pm_ctx *c, double *ke, double *pe)
 
 int pm_forces_ngp(pm_ctx *c)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     HIP_TRY(c, hipSetDevice(c->device));
     stage_timer t(c, PM_STAGE_GATHER);
@@ -492,6 +526,7 @@ int pm_forces_ngp(pm_ctx *c)
 
 int pm_deposit_ngp(pm_ctx *c)
 {
+    TRY(whole_mesh(c));
     TRY(need_particles(c));
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(dalloc(c, &c->density64, (size_t)c->g.M));

@@ -118,7 +118,8 @@ struct pm_ctx {
 size_t pm_heavy_row_entries(int G, int64_t cap);
 size_t pm_unit_rows(int G, int64_t cap);
 
-void pm_set_create_error(const std::string &msg);   // what pm_last_error(NULL) reports
+void pm_set_create_error(const std::string &msg);
+pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab);   // what pm_last_error(NULL) reports
 
 // ---- launchers (each enqueues on ctx->stream and returns a hipError_t) ----------------------
 // stage -> records: positions (n,3) of the given dtype + masses (or ones), velocities (or zeros) + iota ids

@@ -124,11 +124,8 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
     }
     // the hand-written transforms cover whole groups of 16 rows
     if (pm_fft_custom_supported(grid_size) && ((int64_t)nplanes * grid_size) % 16 != 0) flags |= PM_FLAG_ROCFFT_ONLY;
-    pm_ctx *c = pm_create(grid_size, box_size, n_capacity, device, flags & ~(unsigned)PM_FLAG_FUSED_GRADIENT);
+    pm_ctx *c = pm_create_planes(grid_size, box_size, n_capacity, device, flags & ~(unsigned)PM_FLAG_FUSED_GRADIENT, plane0, nplanes, true);
     if (!c) return nullptr;
-    c->slab = true;
-    c->nslabs = grid_size / nplanes;
-    c->g.i0 = plane0; c->g.Gs = nplanes; c->g.Gd = nplanes + 1; c->g.lo = 1;
     auto setup = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
         c->outbox_cap = c->cap / 4 + 1024;
