@@ -223,6 +223,22 @@ def test_full_size_properties(pm):
         assert np.abs(sim.velocities() - vo).max() <= 1e-5 * np.abs(vo).max()
 
 
+def test_correctness_configuration_100_steps(pm):
+    """Uniform random 1M particles on 128^3, 100 steps of main.py:50-60: the GPU trajectory against the oracle's,
+    1e-5 L on positions and 1e-5 max|v| on velocities at the end (and at step 10, where nothing has had time to grow)."""
+    n, G, L, dt = 1_000_000, 128, 10000, 0.005
+    pos, vel, mass = _uniform(n, L)
+    xo, vo = pos, vel
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+        for k in range(1, 101):
+            xo, vo = O.pm_step(xo, vo, mass, G, L, dt)
+            if k in (10, 100):
+                sim.step(dt, 10 if k == 10 else 90)
+                dx = np.abs(sim.positions().astype(np.float64) - xo)
+                assert np.minimum(dx, L - dx).max() <= 1e-5 * L, k
+                assert np.abs(sim.velocities() - vo).max() <= 1e-5 * np.abs(vo).max(), k
+
+
 def test_headline_size_properties(pm):
     """The headline configuration itself (two-galaxy collision, N = 16,777,216 on 512^3) through properties that do
     not need the oracle at that size: mass conservation of the deposit, sortedness and completeness of the cell order,
