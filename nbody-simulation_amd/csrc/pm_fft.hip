@@ -47,10 +47,23 @@ struct col_pass {
 };
 
 // Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 8 at N = 512, 16 at N = 1024).  A column is
-// worked on by TPC = N / 32 threads, each holding 32 of its elements; a block is 16 columns = 16 TPC threads.
-template <int N> struct col_plan {
+// worked on by TPC = N / EPT threads, each holding EPT of its elements; a block is 16 columns = 16 TPC threads
+// (512 or 1024 threads: more waves per CU overlap one tile's loads with another's butterflies better than the 32
+// elements per thread that the registers would allow).
+// elements of a column per thread, per pass (forward, forward + Green + inverse, inverse) at N = 512; 16 at N = 1024
+#ifndef PM_EPT_FWD
+#define PM_EPT_FWD 8
+#endif
+#ifndef PM_EPT_GREEN
+#define PM_EPT_GREEN 16
+#endif
+#ifndef PM_EPT_INV
+#define PM_EPT_INV 8
+#endif
+template <int N, int DIR, bool GREEN> struct col_plan {
+    static constexpr int EPT = N != 512 ? 16 : GREEN ? PM_EPT_GREEN : DIR < 0 ? PM_EPT_FWD : PM_EPT_INV;
     static constexpr int R1 = N / 64;                   // first radix
-    static constexpr int TPC = N / 32;                  // threads per column
+    static constexpr int TPC = N / EPT;                 // threads per column
     static constexpr int THREADS = COLS * TPC;
     static constexpr int NB1 = (N / R1) / TPC;          // butterflies per thread in stage 1
     static constexpr int NB = (N / 8) / TPC;            // ... in stages 2 and 3 (= 4)
@@ -59,13 +72,13 @@ template <int N> struct col_plan {
 
 // Thread t owns column c = t & 15; jl = t >> 4 is its place among the column's threads.  Stage 1
 // (radix R1, no twiddles) takes butterflies j = jl + TPC b and rows j + 64 r; stages 2 and 3 (radix 8)
-// take j = jl + TPC b and rows j + (N/8) r.  After stage 3 the thread holds the rows jl + TPC m, m < 32:
+// take j = jl + TPC b and rows j + (N/8) r.  After stage 3 the thread holds the rows jl + TPC m, m < EPT:
 // exactly the inputs of its stage-1 butterflies, which is what lets the Green pass turn round in registers.
 template <int N, int DIR, bool GREEN>
-__global__ void __launch_bounds__(col_plan<N>::THREADS, N == 512 ? 2 : 1)
+__global__ void __launch_bounds__((col_plan<N, DIR, GREEN>::THREADS))
 k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 {
-    using plan = col_plan<N>;
+    using plan = col_plan<N, DIR, GREEN>;
     constexpr int R1 = plan::R1, TPC = plan::TPC, NB1 = plan::NB1, NB = plan::NB, Q = N / 8;
     extern __shared__ float2 lds[];                 // [N][COLS] tile, then the N twiddles
     float2 *tile = lds;
@@ -78,7 +91,8 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 
     for (int q = t; q < N; q += plan::THREADS) tw[q] = twiddle[q];
 
-    float2 v[32];
+    constexpr int EPT = plan::EPT;
+    float2 v[EPT];
     // ---- stage 1 inputs from global: v[b * R1 + r] = row jl + TPC b + 64 r
 #pragma unroll
     for (int b = 0; b < NB1; ++b)
@@ -159,11 +173,11 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
             }
         if constexpr (R1 != 8) {
             // from "row jl + TPC (b + 4 r)" to the stage-1 order "row jl + TPC (b' + NB1 r')"
-            float2 u[32];
+            float2 u[EPT];
 #pragma unroll
-            for (int m = 0; m < 32; ++m) u[(m % NB1) * R1 + m / NB1] = v[(m % NB) * 8 + m / NB];
+            for (int m = 0; m < EPT; ++m) u[(m % NB1) * R1 + m / NB1] = v[(m % NB) * 8 + m / NB];
 #pragma unroll
-            for (int m = 0; m < 32; ++m) v[m] = u[m];
+            for (int m = 0; m < EPT; ++m) v[m] = u[m];
         }
         __syncthreads();            // every thread has read its stage-3 inputs
         stage1_out(inv_t{});
@@ -252,11 +266,11 @@ hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
     static bool attr[64] = {};                       // the attribute is per device
     const int dev = c->device & 63;
     if (!attr[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N, DIR, GREEN>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr[dev] = true;
     }
-    k_col_fft<N, DIR, GREEN><<<blocks, col_plan<N>::THREADS, col_plan<N>::LDS_BYTES, c->stream>>>(p, c->twiddle);
+    k_col_fft<N, DIR, GREEN><<<blocks, col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(p, c->twiddle);
     return hipGetLastError();
 }
 
