@@ -209,7 +209,10 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 //   Z[k] = (X[k] + conj X[M-k]) + i w^-k (X[k] - conj X[M-k]),  z = unnormalised inverse FFT of Z.
 // Every global access of a wave is a contiguous 512-byte run.
 
-constexpr int ROWS_PER_WAVE = 4;
+#ifndef PM_ROWS_PER_WAVE
+#define PM_ROWS_PER_WAVE 1
+#endif
+constexpr int ROWS_PER_WAVE = PM_ROWS_PER_WAVE;
 
 template <int N>
 __global__ void __launch_bounds__(FFT_BLOCK)
