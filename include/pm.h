@@ -168,6 +168,10 @@ int pm_stage_times(pm_ctx *ctx, float *ms, int *calls);
 /* Replace the flags given to pm_create (e.g. switch stage timing on for a profiling pass). */
 int pm_set_flags(pm_ctx *ctx, unsigned flags);
 
+/* Run the context's work on the caller's HIP stream (a hipStream_t, NULL for the default stream) instead of the
+ * stream the context made for itself: its kernels are then ordered with whatever else the caller puts on that
+ * stream, and the pm_slab_* calls that fill or read caller-owned device buffers no longer wait for the device. */
+int pm_set_stream(pm_ctx *ctx, void *hip_stream);
 int pm_synchronize(pm_ctx *ctx);
 int64_t pm_num_particles(const pm_ctx *ctx);
 const char *pm_last_error(const pm_ctx *ctx);

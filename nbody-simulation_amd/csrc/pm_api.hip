@@ -218,7 +218,7 @@ void pm_destroy(pm_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream);
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
@@ -236,13 +236,26 @@ void pm_destroy(pm_ctx *c)
     for (int s = 0; s < PM_NSTAGES; ++s)
         for (int k = 0; k < 2; ++k)
             if (c->ev[s][k]) hipEventDestroy(c->ev[s][k]);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
 pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags)
 {
     return pm_create_planes(grid_size, box_size, n_capacity, device, flags, 0, grid_size, false);
+}
+
+int pm_set_stream(pm_ctx *c, void *hip_stream)
+{
+    if (!c) return PM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < PM_NSTAGES; ++s) stage_timer::flush(c, s);
+    if (c->own_stream && c->stream) HIP_TRY(c, hipStreamDestroy(c->stream));
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    if (c->info) FFT_TRY(c, rocfft_execution_info_set_stream(c->info, c->stream));
+    return PM_OK;
 }
 
 int pm_synchronize(pm_ctx *c)

@@ -49,6 +49,7 @@ struct pm_ctx {
     int64_t cap = 0;    // particle capacity
     int64_t n = 0;      // particles held
     hipStream_t stream = nullptr;
+    bool own_stream = true;     // false after pm_set_stream: the caller's stream, which orders this context's work with the caller's
 
     // Particle state, double-buffered: `cur` is the live set, 1-cur the target of the next
     // reorder.  Positions are float32 except between pm_set_particles(PM_F64) and the first

@@ -35,6 +35,14 @@ int fail(pm_ctx *c, int code, const std::string &msg)
 
 #define TRY(expr) do { int r_ = (expr); if (r_ != PM_OK) return r_; } while (0)
 
+// A call that hands a device buffer back to the caller waits for the work that fills it -- unless the context
+// works on the caller's own stream (pm_set_stream), which orders it with whatever the caller does next.
+int done(pm_ctx *c)
+{
+    if (c->own_stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
 int need_slab(pm_ctx *c)
 {
     if (!c) return PM_EINVAL;
@@ -200,7 +208,7 @@ int pm_slab_planes(pm_ctx *c, int which, int first, int count, void *device_buff
     if (op == 0) HIP_TRY(c, hipMemcpyAsync(device_buffer, mesh, bytes, hipMemcpyDeviceToDevice, c->stream));
     else if (op == 1) HIP_TRY(c, hipMemcpyAsync(mesh, device_buffer, bytes, hipMemcpyDeviceToDevice, c->stream));
     else HIP_TRY(c, pm_launch_add(c, mesh, (const float *)device_buffer, (int64_t)count * (int64_t)plane));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(done(c));
     return PM_OK;
 }
 
@@ -235,7 +243,7 @@ int pm_slab_pack(pm_ctx *c, void *device_blocks)
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, pm_launch_transpose_pack(c, c->spectrum, (float2 *)device_blocks, false));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(done(c));
     return PM_OK;
 }
 
@@ -263,7 +271,7 @@ int pm_slab_solve_x(pm_ctx *c, void *device_spectrum_t)
         HIP_TRY(c, pm_launch_green_t(c, s, c->g.i0, c->g.Gs));
         FFT_TRY(c, rocfft_execute(c->slab_invx, io, nullptr, c->info));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(done(c));
     return PM_OK;
 }
 
@@ -316,7 +324,7 @@ int pm_slab_inbox(pm_ctx *c, const void *device_records, int64_t n)
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->v_stale) return fail(c, PM_ESTATE, "pm_slab_inbox belongs between the drift and the next deposit");
     HIP_TRY(c, pm_launch_append(c, (const pm_migrant *)device_records, n));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(done(c));
     c->n += n;
     c->binned = false;
     return PM_OK;

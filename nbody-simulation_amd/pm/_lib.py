@@ -54,6 +54,7 @@ SIGNATURES = {
     "pm_slab_pitch": (_int, [_c_p]),
     "pm_stage_times": (_int, [_c_p, _c_p, _c_p]),
     "pm_set_flags": (_int, [_c_p, ctypes.c_uint]),
+    "pm_set_stream": (_int, [_c_p, _c_p]),
     "pm_synchronize": (_int, [_c_p]),
     "pm_num_particles": (_i64, [_c_p]),
     "pm_last_error": (ctypes.c_char_p, [_c_p]),

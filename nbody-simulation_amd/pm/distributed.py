@@ -44,6 +44,8 @@ class HipSlabEngine:
         self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, 0, self.i0, self.Gs)
         if not self.ctx:
             raise _lib.PMError("pm_create_slab failed: " + (self.lib.pm_last_error(None) or b"?").decode())
+        # the library works on torch's current stream: its kernels, torch's copies and the collectives order themselves
+        self._check(self.lib.pm_set_stream(self.ctx, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         self.pitch = self.lib.pm_slab_pitch(self.ctx)
         f32 = dict(dtype=torch.float32, device=self.device)
         self._blocks = [torch.empty((self.Gs * self.G * self.pitch, 2), **f32) for _ in range(2)]
@@ -58,9 +60,7 @@ class HipSlabEngine:
         _lib.check(self.ctx, rc)
 
     def _sync(self):
-        # The library works on its own stream: before it reads or writes a tensor, everything torch has queued on
-        # that tensor (copies, cats, collectives) has to be done.  The library's calls wait for their own work.
-        torch.cuda.synchronize(self.device)
+        pass        # nothing to wait for: one stream carries torch's work and the library's
 
     @property
     def n(self):
