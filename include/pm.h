@@ -139,7 +139,10 @@ int pm_slab_planes(pm_ctx *ctx, int which, int first, int count, void *device_bu
  * half spectrum (nplanes, G, pitch); dir > 0 half spectrum -> owned potential planes. */
 int pm_slab_fft2(pm_ctx *ctx, int dir);
 /* The half spectrum as G/nplanes blocks for an all-to-all (block p: rows p*nplanes.. of every owned
- * plane; nplanes*G*pitch complex64 in all), and back from the blocks the inverse all-to-all delivers. */
+ * plane; nplanes*G*pitch complex64 in all), and back from the blocks the inverse all-to-all delivers.
+ * Call order: pm_slab_fft2(-1), pm_slab_pack, [all-to-all], pm_slab_solve_x, [all-to-all], pm_slab_unpack,
+ * pm_slab_fft2(+1) -- where the hand-written transforms apply (grid 512 / 1024, nplanes a power of two) the
+ * passes along y are done by pack and unpack themselves, straight into and out of the blocks. */
 int pm_slab_pack(pm_ctx *ctx, void *device_blocks);
 int pm_slab_unpack(pm_ctx *ctx, const void *device_blocks);
 /* compute_potential, the x part (functions.py:75-89), in place on what the all-to-all delivered:

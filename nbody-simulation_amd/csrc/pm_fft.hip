@@ -44,6 +44,11 @@ struct col_pass {
     int outer0;             // mesh index of outer index 0 (Green multiply)
     int tile0;              // first column tile of this launch (a launch may cover a range of tiles only)
     int ntiles;             // column tiles per outer index in this launch
+    // BLK != 0 (slab decomposition, transform along y): the other side of the pass is not `spec` but the buffer of an
+    // all-to-all, `blocks`, laid out (G / Gs, Gs planes, Gs rows, pitch): row y of plane `outer` lies in block y / Gs
+    float2 *blocks;
+    int gs_shift;           // log2 Gs
+    int64_t block_stride;   // Gs * Gs * pitch
 };
 
 // Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 8 at N = 512, 16 at N = 1024).  A column is
@@ -74,7 +79,8 @@ template <int N, int DIR, bool GREEN> struct col_plan {
 // (radix R1, no twiddles) takes butterflies j = jl + TPC b and rows j + 64 r; stages 2 and 3 (radix 8)
 // take j = jl + TPC b and rows j + (N/8) r.  After stage 3 the thread holds the rows jl + TPC m, m < EPT:
 // exactly the inputs of its stage-1 butterflies, which is what lets the Green pass turn round in registers.
-template <int N, int DIR, bool GREEN>
+// BLK = 1: the results go to p.blocks instead of back to p.spec; BLK = 2: the inputs come from p.blocks.
+template <int N, int DIR, bool GREEN, int BLK = 0>
 __global__ void __launch_bounds__((col_plan<N, DIR, GREEN>::THREADS))
 k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 {
@@ -88,6 +94,11 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
     const int col = ct * COLS + c;
     const bool valid = col < p.ncols;
     float2 *g = p.spec + (int64_t)outer * p.outer_stride + col;
+    // the same column in the all-to-all buffer: plane `outer`'s rows of block b start at (b * Gs + outer) * Gs * pitch
+    float2 *gb = BLK ? p.blocks + ((int64_t)outer << p.gs_shift) * p.row_stride + col : nullptr;
+    auto in_blocks = [&](int row) -> float2 & {
+        return gb[(int64_t)(row >> p.gs_shift) * p.block_stride + (int64_t)(row & ((1 << p.gs_shift) - 1)) * p.row_stride];
+    };
 
     for (int q = t; q < N; q += plan::THREADS) tw[q] = twiddle[q];
 
@@ -99,7 +110,8 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 #pragma unroll
         for (int r = 0; r < R1; ++r) {
             int row = jl + TPC * b + 64 * r;
-            v[b * R1 + r] = valid ? g[(int64_t)row * p.row_stride] : make_float2(0.0f, 0.0f);
+            if (BLK == 2) v[b * R1 + r] = valid ? in_blocks(row) : make_float2(0.0f, 0.0f);
+            else v[b * R1 + r] = valid ? g[(int64_t)row * p.row_stride] : make_float2(0.0f, 0.0f);
         }
 
     auto stage1_out = [&](auto dir) {
@@ -193,7 +205,8 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 int row = jl + TPC * b + Q * r;
-                g[(int64_t)row * p.row_stride] = v[b * 8 + r];
+                if (BLK == 1) in_blocks(row) = v[b * 8 + r];
+                else g[(int64_t)row * p.row_stride] = v[b * 8 + r];
             }
     }
 }
@@ -263,17 +276,17 @@ k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, con
     }
 }
 
-template <int N, int DIR, bool GREEN>
+template <int N, int DIR, bool GREEN, int BLK = 0>
 hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
 {
     static bool attr[64] = {};                       // the attribute is per device
     const int dev = c->device & 63;
     if (!attr[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N, DIR, GREEN>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N, DIR, GREEN>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr[dev] = true;
     }
-    k_col_fft<N, DIR, GREEN><<<blocks, col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(p, c->twiddle);
+    k_col_fft<N, DIR, GREEN, BLK><<<blocks, col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(p, c->twiddle);
     return hipGetLastError();
 }
 
@@ -376,6 +389,22 @@ hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes
     col_pass p = pass_for(c, spec);
     p.outer_stride = (int64_t)G * P; p.row_stride = P;
     return launch_col_any(c, dir < 0 ? -1 : 1, p, planes * p.tiles);
+}
+
+// The pass along y of `planes` planes with the all-to-all buffer on one side: forward from spec into blocks, or inverse
+// from blocks into spec.  planes must be a power of two.
+hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *blocks, int planes)
+{
+    const int G = c->g.G, P = c->g.Ghp;
+    col_pass p = pass_for(c, spec);
+    p.outer_stride = (int64_t)G * P; p.row_stride = P;
+    p.blocks = blocks;
+    p.gs_shift = 0;
+    while ((1 << p.gs_shift) < planes) ++p.gs_shift;
+    p.block_stride = (int64_t)planes * planes * P;
+    const int nb = planes * p.tiles;
+    if (G == 512) return dir < 0 ? launch_col<512, -1, false, 1>(c, p, nb) : launch_col<512, 1, false, 2>(c, p, nb);
+    return dir < 0 ? launch_col<1024, -1, false, 1>(c, p, nb) : launch_col<1024, 1, false, 2>(c, p, nb);
 }
 
 // spec_t: (G, ny, Ghp), transform axis first; its rows are mesh rows y0 .. y0 + ny - 1

@@ -101,6 +101,7 @@ struct pm_ctx {
     // slab decomposition (pm_create_slab)
     bool slab = false;
     int nslabs = 1;
+    bool y_in_exchange = false;         // hand-written transforms: the passes along y read / write the all-to-all buffer themselves
     bool slab_check = false;            // the next deposit verifies that every particle lies in the slab
     int64_t leaving = 0;                // particles with the "not mine" key in the live set (they sort to the tail)
     pm_migrant *outbox = nullptr;       // particles that left the slab in the last drift, in no particular order
@@ -142,6 +143,7 @@ hipError_t pm_launch_col_fft(pm_ctx *c, int dir);
 hipError_t pm_launch_row_fft_planes(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int planes);
 hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes);
 hipError_t pm_launch_solve_x(pm_ctx *c, float2 *spec_t, int y0, int ny);
+hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *blocks, int planes);
 hipError_t pm_launch_add(pm_ctx *c, float *mesh, const float *other, int64_t n);
 hipError_t pm_launch_green_t(pm_ctx *c, float2 *spec_t, int y0, int ny);
 hipError_t pm_launch_transpose_pack(pm_ctx *c, const float2 *spec, float2 *out, bool unpack);

@@ -134,6 +134,7 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
     if (pm_fft_custom_supported(grid_size) && ((int64_t)nplanes * grid_size) % 16 != 0) flags |= PM_FLAG_ROCFFT_ONLY;
     pm_ctx *c = pm_create_planes(grid_size, box_size, n_capacity, device, flags & ~(unsigned)PM_FLAG_FUSED_GRADIENT, plane0, nplanes, true);
     if (!c) return nullptr;
+    c->y_in_exchange = c->fft_custom && (nplanes & (nplanes - 1)) == 0;
     auto setup = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
         c->outbox_cap = c->cap / 4 + 1024;
@@ -221,11 +222,12 @@ int pm_slab_fft2(pm_ctx *c, int dir)
     const size_t plane = (size_t)c->g.G * c->g.G;
     float *pot = c->potential + plane;
     if (c->fft_custom) {
+        // (with y_in_exchange the passes along y belong to pm_slab_pack / pm_slab_unpack)
         if (dir < 0) {
             HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density, nullptr, c->spectrum, c->g.Gs));
-            HIP_TRY(c, pm_launch_col_fft_planes(c, -1, c->spectrum, c->g.Gs));
+            if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, -1, c->spectrum, c->g.Gs));
         } else {
-            HIP_TRY(c, pm_launch_col_fft_planes(c, 1, c->spectrum, c->g.Gs));
+            if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, 1, c->spectrum, c->g.Gs));
             HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, pot, c->spectrum, c->g.Gs));
         }
     } else {
@@ -242,7 +244,8 @@ int pm_slab_pack(pm_ctx *c, void *device_blocks)
 {
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, pm_launch_transpose_pack(c, c->spectrum, (float2 *)device_blocks, false));
+    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->spectrum, (float2 *)device_blocks, c->g.Gs));
+    else HIP_TRY(c, pm_launch_transpose_pack(c, c->spectrum, (float2 *)device_blocks, false));
     TRY(done(c));
     return PM_OK;
 }
@@ -251,7 +254,8 @@ int pm_slab_unpack(pm_ctx *c, const void *device_blocks)
 {
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, pm_launch_transpose_pack(c, (const float2 *)device_blocks, c->spectrum, true));
+    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs));
+    else HIP_TRY(c, pm_launch_transpose_pack(c, (const float2 *)device_blocks, c->spectrum, true));
     return PM_OK;
 }
 
