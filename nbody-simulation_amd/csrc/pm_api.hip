@@ -182,7 +182,11 @@ static int create_impl(pm_ctx *c)
 // A context for planes [plane0, plane0 + nplanes) of the mesh: all of them (pm_create) or a slab (pm_create_slab).
 pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab)
 {
-    if (grid_size < 2 || grid_size > 1625) { fail(nullptr, PM_EINVAL, "grid_size must be in [2, 1625] (cell keys are 32-bit)"); return nullptr; }
+    // cell keys are 32-bit: one key per cell of the planes this context owns, and one more
+    if (grid_size < 2 || nplanes < 1 || (int64_t)nplanes * grid_size * grid_size + 1 >= ((int64_t)1 << 32)) {
+        fail(nullptr, PM_EINVAL, slab ? "nplanes * grid_size^2 must be below 2^32 (cell keys are 32-bit)" : "grid_size must be in [2, 1625] (cell keys are 32-bit)");
+        return nullptr;
+    }
     if (!(box_size > 0.0) || !std::isfinite(box_size)) { fail(nullptr, PM_EINVAL, "box_size must be positive and finite"); return nullptr; }
     if (n_capacity < 0 || n_capacity >= ((int64_t)1 << 31)) { fail(nullptr, PM_EINVAL, "n_capacity must be in [0, 2^31-1]"); return nullptr; }
     int ndev = 0;

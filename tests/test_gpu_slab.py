@@ -132,6 +132,33 @@ def test_slab_collectives_over_rccl_single_rank(tmp_path):
     check("g32", [out])
 
 
+def test_slab_errors():
+    """Argument and state errors of the pm_slab_* entry points come back as codes with a message."""
+    import ctypes
+    import pm
+    from pm import _lib
+    lib = pm.load()
+    assert not lib.pm_create_slab(32, 100.0, 100, 0, 0, 0, 5)              # 5 does not divide 32
+    assert b"nplanes" in lib.pm_last_error(None)
+    assert not lib.pm_create_slab(32, 100.0, 100, 0, 0, 4, 8)              # plane0 not a multiple of nplanes
+    assert not lib.pm_create_slab(4, 100.0, 100, 0, 0, 0, 2)               # no room for the three extra potential planes
+    ctx = lib.pm_create_slab(32, 100.0, 100, 0, 0, 8, 8)
+    assert ctx
+    try:
+        assert lib.pm_step(ctx, 0.1, 1) == 5 and b"slab" in lib.pm_last_error(ctx)         # PM_ESTATE: whole-mesh call
+        assert lib.pm_slab_planes(ctx, 0, 8, 2, ctypes.c_void_p(16), 0) == 1                 # PM_EINVAL: 9 density planes only
+        assert lib.pm_slab_planes(ctx, 1, 0, 11, None, 0) == 1                               # NULL buffer
+        pos = np.array([[50.0, 1.0, 1.0]], np.float32)                                       # plane 16: not in [8, 16)
+        vel = np.zeros((1, 3), np.float32)
+        assert lib.pm_slab_set_particles(ctx, pos.ctypes.data, vel.ctypes.data, None, None, 1) == 0
+        assert lib.pm_slab_deposit(ctx) == 1 and b"other slabs" in lib.pm_last_error(ctx)
+        whole = lib.pm_create(32, 100.0, 100, 0, 0)
+        assert lib.pm_slab_deposit(whole) == 5                                               # not a slab context
+        lib.pm_destroy(whole)
+    finally:
+        lib.pm_destroy(ctx)
+
+
 def test_slab_matches_oracle_world1(tmp_path):
     """The same g32 run against the CPU oracle."""
     from oracle import pm_oracle as O
