@@ -139,8 +139,11 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, planes * G + 1));
     TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G, cap)));
-    TRY(dalloc(c, &c->counters, 1));
-    TRY(dalloc(c, &c->unit_rows, pm_unit_rows(G, cap) * (size_t)G));
+    TRY(dalloc(c, &c->counters, 64));
+    TRY(dalloc(c, &c->row_unit, planes * G + 1));
+    TRY(dalloc(c, &c->unit_src, pm_max_units(cap)));
+    TRY(dalloc(c, &c->unit_rows, pm_max_units(cap) * 4 * (size_t)G));
+    TRY(dalloc(c, &c->light_rows, pm_heavy_row_entries(G, cap) * (size_t)G));
     // a slab context keeps one more density plane and three more potential planes than it owns, and no gradient meshes
     TRY(dalloc(c, &c->density, (planes + 1) * plane));
     TRY(dalloc(c, &c->potential, (planes + 3) * plane));
@@ -226,7 +229,7 @@ void pm_destroy(pm_ctx *c)
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
-    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows);
+    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage); hipFree(c->diag); hipFree(c->density64);

@@ -74,9 +74,12 @@ struct pm_ctx {
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
-    uint2 *heavy_rows = nullptr;        // density rows fed by more particles than one wave should walk: (row, first unit)
-    unsigned long long *counters = nullptr;     // entries of heavy_rows (high word) and units handed out (low word)
-    double *unit_rows = nullptr;        // one row of G doubles per unit of a listed row
+    uint32_t *row_unit = nullptr;       // per mesh row: first unit of a crowded row, or none
+    uint32_t *unit_src = nullptr;       // per unit: the mesh row it is a part of
+    uint2 *heavy_rows = nullptr;        // density rows with a crowded source: (row, has a partial sum in light_rows)
+    uint32_t *counters = nullptr;       // units handed out, density rows listed (64 words)
+    double *unit_rows = nullptr;        // four rows of G doubles per unit
+    double *light_rows = nullptr;       // one row of G doubles per listed density row
 
     // meshes
     float *density = nullptr, *potential = nullptr, *grad[3] = {};
@@ -118,7 +121,7 @@ struct pm_ctx {
 };
 
 size_t pm_heavy_row_entries(int G, int64_t cap);
-size_t pm_unit_rows(int G, int64_t cap);
+size_t pm_max_units(int64_t cap);
 
 void pm_set_create_error(const std::string &msg);
 pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab);   // what pm_last_error(NULL) reports

@@ -164,16 +164,16 @@ __global__ void k_cell_keys(const pm_prec<TP> *__restrict__ P, uint32_t *__restr
 // here and not once per visit there.  The velocity records are not moved here: the gather, which reads and writes every one of
 // them anyway, reads record src[r] and writes it to slot r (k_move_v does it when no gather follows).
 //
-// Tuning: a density row fed by at most PM_PACKED_MAX particles is walked one particle per lane;
-// one fed by more than PM_LIGHT_MAX is cut into units of PM_UNIT particles.
+// Tuning: a density row fed by at most PM_PACKED_MAX particles is walked one particle per lane; a
+// mesh row that holds more than PM_HEAVY_SRC particles is deposited on its own, in units of PM_UNIT.
 #ifndef PM_PACKED_MAX
 #define PM_PACKED_MAX 512
 #endif
-#ifndef PM_LIGHT_MAX
-#define PM_LIGHT_MAX 8192
+#ifndef PM_HEAVY_SRC
+#define PM_HEAVY_SRC 2048
 #endif
 #ifndef PM_UNIT
-#define PM_UNIT 4096
+#define PM_UNIT 6144
 #endif
 #ifndef PM_UNIT_GRID
 #define PM_UNIT_GRID 2048
@@ -234,11 +234,17 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 // registers and adds to LDS only when the cell changes; what a lane still holds at the end of the
 // four goes through add_pass, which first combines neighbouring lanes that hold the same cell.
 //
-// A row fed by more than LIGHT_MAX particles would keep its wave busy long after the others have
-// finished.  Such rows are listed instead; their particles (the four runs as one sequence) are cut
-// into units of UNIT, k_deposit_units sums each unit into a float64 row of its own in global
-// memory, and k_sum_units adds a row's units in order and emits the row.
-constexpr uint32_t PACKED_MAX = PM_PACKED_MAX, LIGHT_MAX = PM_LIGHT_MAX, UNIT = PM_UNIT;
+//
+// A crowded mesh row (more than HEAVY_SRC particles) would keep the waves of the four density rows it
+// feeds busy long after the others have finished, each of them reading the same particles.  Such a
+// source row is cut into units of UNIT particles instead (k_plan_units); k_deposit_units reads every
+// unit once and sums it into four float64 rows of its own in global memory, one per (di,dj); the waves
+// of the density rows leave crowded sources out, and where a density row has one, its sum is put
+// together by k_sum_units: what its wave summed from the other sources, then the units of its crowded
+// sources, in a fixed order.
+constexpr uint32_t PACKED_MAX = PM_PACKED_MAX, HEAVY_SRC = PM_HEAVY_SRC, UNIT = PM_UNIT, NO_UNIT = 0xffffffffu;
+constexpr int UNIT_BLOCK = 128;         // two waves, each with four LDS rows
+constexpr int COUNTER_UNITS = 0, COUNTER_ROWS = 32;     // counters[]: units handed out, density rows listed (own 128-byte lines)
 
 __device__ __forceinline__ void lds_add(double *p, double v)
 {
@@ -270,11 +276,41 @@ __device__ __forceinline__ void add_pass(double *acc, int G, int k, double lo, d
     }
 }
 
+// The same for the four density rows a source row feeds: acc holds them one after the other.
+__device__ __forceinline__ void add_pass4(double *acc, int G, int k, double (&lo)[4], double (&hi)[4], bool add)
+{
+    const int lane = lane_id();
+    int kprev = __shfl_up(k, 1);
+    const unsigned long long dup = __ballot(lane > 0 && kprev == k);
+    if (__popcll(dup) > 8) {
+        const unsigned long long starts = ~dup;
+        const int start = 63 - __clzll((long long)(starts & ((2ull << lane) - 1ull)));
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const bool take = lane - d >= start;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double lu = __shfl_up(lo[q], d), hu = __shfl_up(hi[q], d);
+                if (take) { lo[q] += lu; hi[q] += hu; }
+            }
+        }
+        add = add && (lane == 63 || ((starts >> (lane + 1)) & 1ull));
+    }
+    if (add) {
+        const int k1 = (k + 1 == G) ? 0 : k + 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lds_add(&acc[q * G + k], lo[q]);
+            lds_add(&acc[q * G + k1], hi[q]);
+        }
+    }
+}
+
 // beg/end: particle range of the four source rows of a density row, in the order
 // (di,dj) = (0,0) (1,0) (0,1) (1,1); key0: the key of cell k = 0 of each source row.
-struct row_runs { uint32_t beg[4], end[4], key0[4], longest; };
+struct row_runs { uint32_t beg[4], end[4], key0[4], unit[4], longest; };    // unit: first unit of a crowded source, or NO_UNIT
 
-__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uint32_t row, const pm_geom &g)
+__device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, uint32_t row, const pm_geom &g)
 {
     const int G = g.G;
     int i = (int)(row / (uint32_t)G), j = (int)(row % (uint32_t)G);
@@ -290,6 +326,7 @@ __device__ __forceinline__ row_runs runs_of(const uint32_t *__restrict__ rs, uin
     for (int q = 0; q < 4; ++q) {
         const bool has = (q & 1) ? has_im : has_i;
         t.beg[q] = has ? rs[src[q]] : 0u; t.end[q] = has ? rs[src[q] + 1] : 0u;
+        t.unit[q] = has ? row_unit[src[q]] : NO_UNIT;
         t.key0[q] = src[q] * (uint32_t)G;
         uint32_t len = t.end[q] - t.beg[q];
         t.longest = len > t.longest ? len : t.longest;
@@ -410,6 +447,58 @@ __device__ __forceinline__ void deposit_chunks(const pm_frac *__restrict__ F, co
     }
 }
 
+// Particles [beg, end) of one source row into the four LDS rows acc[q * G ...] of the density rows it feeds,
+// q = di + 2 dj: every particle is read once and all eight corner masses are formed from it.
+__device__ __forceinline__ void deposit_chunks4(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
+                                                uint32_t beg, uint32_t end, uint32_t key0, int G, double *acc)
+{
+    if (beg >= end) return;
+    const int lane = lane_id();
+    const int idle = 0x7fffffff - lane;
+    uint32_t base = beg & ~3u;
+    chunk_t cur = load_chunk(F, key, base, end);
+    while (base < end) {                                        // wave-uniform
+        const chunk_t c = cur;
+        if (base + 256 < end) cur = load_chunk(F, key, base + 256, end);
+        const uint32_t r = base + 4u * lane;
+        const uint32_t kk[4] = {c.key.x, c.key.y, c.key.z, c.key.w};
+        int ck = idle;
+        double slo[4] = {0.0, 0.0, 0.0, 0.0}, shi[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool valid = r + t >= beg && r + t < end;
+            int k = idle;
+            double lo[4] = {0.0, 0.0, 0.0, 0.0}, hi[4] = {0.0, 0.0, 0.0, 0.0};
+            if (valid) {
+                k = (int)(kk[t] - key0);
+                // mass * wx * wy * wz, left to right (functions.py:61-68), as corner_pair forms them
+                const double dx = (double)c.f[t].dx, dy = (double)c.f[t].dy, dz = (double)c.f[t].dz, m = (double)c.f[t].m;
+                const double mx[2] = {m * (1.0 - dx), m * dx}, wy[2] = {1.0 - dy, dy};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double w = mx[q & 1] * wy[q >> 1];
+                    lo[q] = w * (1.0 - dz); hi[q] = w * dz;
+                }
+            }
+            if (k == ck) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { slo[q] += lo[q]; shi[q] += hi[q]; }
+            } else {
+                if (ck != idle) {
+                    const int k1 = (ck + 1 == G) ? 0 : ck + 1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { lds_add(&acc[q * G + ck], slo[q]); lds_add(&acc[q * G + k1], shi[q]); }
+                }
+                ck = k;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { slo[q] = lo[q]; shi[q] = hi[q]; }
+            }
+        }
+        add_pass4(acc, G, ck, slo, shi, ck != idle);
+        base += 256;
+    }
+}
+
 // A summed row leaves the kernel either as G float32 densities (NFFT = 0) or, for G = NFFT = 512 or
 // 1024, already transformed along z: the wave packs the row into NFFT/2 complex numbers, runs the FFT
 // and writes the NFFT/2 + 1 values of the row's half spectrum.  The density mesh is then never written
@@ -449,15 +538,40 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
     }
 }
 
-// One wave per density row; rows cut into units are only listed: entry = (row, index of its first
-// unit).  One 64-bit counter hands out the list slot (high word) and the unit index (low word)
-// together, so the entries are in the order of their unit indices.
+// Crowded source rows get their units: row_unit[row] = index of the row's first unit (NO_UNIT for the other rows),
+// unit_src[u] = the row unit u belongs to.  One counter update per wave.
+__global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32_t *__restrict__ row_unit, uint32_t *__restrict__ unit_src,
+                             uint32_t *__restrict__ counters)
+{
+    const uint32_t row = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t len = row < R ? rs[row + 1] - rs[row] : 0u;
+    const uint32_t units = len > HEAVY_SRC ? (len + UNIT - 1) / UNIT : 0u;
+    uint32_t before = units;                                    // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(before, d);
+        if (lane_id() >= d) before += up;
+    }
+    const uint32_t total = __shfl(before, 63);
+    uint32_t base = 0;
+    if (total) {
+        if (lane_id() == 0) base = atomicAdd(counters + COUNTER_UNITS, total);
+        base = __shfl(base, 0);
+    }
+    if (row >= R) return;
+    const uint32_t first = base + before - units;
+    row_unit[row] = units ? first : NO_UNIT;
+    for (uint32_t u = 0; u < units; ++u) unit_src[first + u] = row;
+}
+
+// One wave per density row.  A row with a crowded source leaves that source out and is listed for
+// k_sum_units: entry = (row, whether the wave has put a sum of the other sources into light_rows[entry]).
 template <int NFFT>
 __global__ void __launch_bounds__(BLOCK)
 k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
-               const uint32_t *__restrict__ rs, float *__restrict__ density,
+               const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, float *__restrict__ density,
                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
-               uint2 *__restrict__ heavy_rows, unsigned long long *__restrict__ heavy_count, pm_geom g)
+               uint2 *__restrict__ heavy_rows, uint32_t *__restrict__ counters, double *__restrict__ light_rows, pm_geom g)
 {
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then the NFFT twiddles
     const int G = g.G;
@@ -472,20 +586,29 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     }
     if (row >= R) return;
     double *acc = lds_rows + (size_t)wave_id() * G;
-    const row_runs t = runs_of(rs, row, g);
-    if (t.longest == 0) {
+    row_runs t = runs_of(rs, row_unit, row, g);
+    bool crowded = false;
+    t.longest = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (t.unit[q] != NO_UNIT) { crowded = true; t.end[q] = t.beg[q]; }     // not walked here
+        const uint32_t len = t.end[q] - t.beg[q];
+        t.longest = len > t.longest ? len : t.longest;
+    }
+    if (t.longest == 0 && !crowded) {
         emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp);
         return;
     }
-    const packed_runs p(t);
-    if (p.total > LIGHT_MAX) {
+    uint32_t entry = 0;
+    if (crowded) {
         if (lane_id() == 0) {
-            const unsigned long long units = (p.total + UNIT - 1) / UNIT;
-            const unsigned long long old = atomicAdd(heavy_count, (1ull << 32) | units);
-            heavy_rows[old >> 32] = make_uint2(row, (uint32_t)old);
+            entry = atomicAdd(counters + COUNTER_ROWS, 1u);
+            heavy_rows[entry] = make_uint2(row, t.longest ? 1u : 0u);
         }
-        return;
+        if (t.longest == 0) return;
+        entry = __builtin_amdgcn_readfirstlane(entry);
     }
+    const packed_runs p(t);
     if (p.total <= PACKED_MAX) {
         const light_t first = p.load(F, key, 0);
         for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
@@ -496,54 +619,46 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         for (int q = 0; q < 4; ++q) deposit_chunks(F, key, t.beg[q], t.end[q], t.key0[q], q & 1, q & 2, G, acc);
     }
     pmfft::wave_sync();
-    emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp);
+    if (crowded) {
+        double *out = light_rows + (size_t)entry * G;
+        for (int c = lane_id(); c < G; c += 64) out[c] = acc[c];
+    } else {
+        emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp);
+    }
 }
 
-// One wave per unit: particles [u * UNIT, (u + 1) * UNIT) of a listed row's packed sequence, summed
-// into the wave's LDS row and written out as G doubles.
-__global__ void __launch_bounds__(BLOCK)
+// One wave per unit of a crowded source row: its particles into four LDS rows, written out as 4 G doubles
+// (unit u, corner q = di + 2 dj -> unit_rows[(4 u + q) G ...]).
+__global__ void __launch_bounds__(UNIT_BLOCK)
 k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key, const uint32_t *__restrict__ rs,
-                const uint2 *__restrict__ heavy_rows, const unsigned long long *__restrict__ heavy_count,
-                double *__restrict__ partial, pm_geom g)
+                const uint32_t *__restrict__ row_unit, const uint32_t *__restrict__ unit_src, const uint32_t *__restrict__ counters,
+                double *__restrict__ unit_rows, pm_geom g)
 {
-    extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles
+    extern __shared__ double lds_rows[];                // per wave four rows of G doubles
     const int G = g.G;
-    double *acc = lds_rows + (size_t)wave_id() * G;
-    const unsigned long long count = *heavy_count;
-    const uint32_t entries = (uint32_t)(count >> 32), units = (uint32_t)count;
-    const uint32_t waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t u = blockIdx.x * (BLOCK / 64) + (uint32_t)wave_id(); u < units; u += waves) {
-        uint32_t lo = 0, hi = entries;                  // the last entry whose first unit is <= u
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (heavy_rows[mid].y <= u) lo = mid; else hi = mid;
-        }
-        const uint2 entry = heavy_rows[lo];
-        const row_runs t = runs_of(rs, entry.x, g);
-        const uint32_t from = (u - entry.y) * UNIT, to = from + UNIT;      // in the packed sequence
-        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
-        uint32_t off = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t len = t.end[q] - t.beg[q];
-            const uint32_t a = from > off ? from - off : 0u, b = to - off < len ? to - off : len;    // to > off always matters only when a < b
-            if (to > off && a < b) deposit_chunks(F, key, t.beg[q] + a, t.beg[q] + b, t.key0[q], q & 1, q & 2, G, acc);
-            off += len;
-        }
+    double *acc = lds_rows + (size_t)wave_id() * 4 * G;
+    const uint32_t units = counters[COUNTER_UNITS];
+    const uint32_t waves = gridDim.x * (UNIT_BLOCK / 64);
+    for (uint32_t u = blockIdx.x * (UNIT_BLOCK / 64) + (uint32_t)wave_id(); u < units; u += waves) {
+        const uint32_t row = unit_src[u];
+        const uint32_t beg = rs[row] + (u - row_unit[row]) * UNIT;
+        const uint32_t last = rs[row + 1], end = beg + UNIT < last ? beg + UNIT : last;
+        for (int c = lane_id(); c < 4 * G; c += 64) acc[c] = 0.0;
+        deposit_chunks4(F, key, beg, end, row * (uint32_t)G, G, acc);
         pmfft::wave_sync();
-        double *out = partial + (size_t)u * G;
-        for (int c = lane_id(); c < G; c += 64) out[c] = acc[c];
+        double *out = unit_rows + (size_t)u * 4 * G;
+        for (int c = lane_id(); c < 4 * G; c += 64) out[c] = acc[c];
         pmfft::wave_sync();
     }
 }
 
-// One block per listed row: its units' rows added in unit order (a thread per column, four loads in
-// flight), then emitted like any other row.
+// One block per listed density row: what its own wave summed, then the units of its crowded sources
+// (q = 0..3, units in order; a thread per column, four loads in flight), then emitted like any other row.
 template <int NFFT>
 __global__ void __launch_bounds__(BLOCK)
-k_sum_units(const uint32_t *__restrict__ rs, const uint2 *__restrict__ heavy_rows, const unsigned long long *__restrict__ heavy_count,
-            const double *__restrict__ partial, float *__restrict__ density, float2 *__restrict__ spectrum,
-            const float2 *__restrict__ twiddle, pm_geom g)
+k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, const uint2 *__restrict__ heavy_rows,
+            const uint32_t *__restrict__ counters, const double *__restrict__ unit_rows, const double *__restrict__ light_rows,
+            float *__restrict__ density, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle, pm_geom g)
 {
     extern __shared__ double lds_rows[];                // one row of G doubles, then the NFFT twiddles
     const int G = g.G;
@@ -551,20 +666,25 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint2 *__restrict__ heavy_row
     if constexpr (NFFT != 0) {
         for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
     }
-    const uint32_t entries = (uint32_t)(*heavy_count >> 32);
+    const uint32_t entries = counters[COUNTER_ROWS];
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
         const uint2 entry = heavy_rows[e];
-        const packed_runs p(runs_of(rs, entry.x, g));
-        const uint32_t units = (p.total + UNIT - 1) / UNIT;
+        const row_runs t = runs_of(rs, row_unit, entry.x, g);
         for (int c = threadIdx.x; c < G; c += BLOCK) {
-            const double *in = partial + (size_t)entry.y * G + c;
-            double sum = 0.0;
-            uint32_t u = 0;
-            for (; u + 4 <= units; u += 4, in += 4 * (size_t)G) {
-                const double v0 = in[0], v1 = in[G], v2 = in[2 * (size_t)G], v3 = in[3 * (size_t)G];
-                sum += v0; sum += v1; sum += v2; sum += v3;
+            double sum = entry.y ? light_rows[(size_t)e * G + c] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (t.unit[q] == NO_UNIT) continue;
+                const uint32_t units = (t.end[q] - t.beg[q] + UNIT - 1) / UNIT;
+                const size_t step = (size_t)4 * G;
+                const double *in = unit_rows + ((size_t)t.unit[q] * 4 + q) * G + c;
+                uint32_t u = 0;
+                for (; u + 4 <= units; u += 4, in += 4 * step) {
+                    const double v0 = in[0], v1 = in[step], v2 = in[2 * step], v3 = in[3 * step];
+                    sum += v0; sum += v1; sum += v2; sum += v3;
+                }
+                for (; u < units; ++u, in += step) sum += in[0];
             }
-            for (; u < units; ++u, in += G) sum += in[0];
             lds_rows[c] = sum;
         }
         __syncthreads();
@@ -851,30 +971,38 @@ hipError_t pm_launch_row_start(pm_ctx *c)
     return hipGetLastError();
 }
 
-// A listed row is fed by more than LIGHT_MAX particles, and every particle feeds four rows.
+// A crowded source row holds more than HEAVY_SRC particles; it has one unit per UNIT particles and a partly
+// filled one; it feeds four density rows.
+size_t pm_max_units(int64_t cap) { return (size_t)(cap / UNIT + cap / HEAVY_SRC + 1); }
 size_t pm_heavy_row_entries(int G, int64_t cap)
 {
-    const size_t by_particles = (size_t)(4 * cap / LIGHT_MAX) + 1, rows = (size_t)(G + 1) * G;
+    const size_t by_particles = (size_t)(4 * (cap / HEAVY_SRC) + 4), rows = (size_t)(G + 1) * G;
     return by_particles < rows ? by_particles : rows;
 }
-
-// Units: one per UNIT particles of a listed row, plus at most one partly filled unit per row.
-size_t pm_unit_rows(int G, int64_t cap) { return (size_t)(4 * cap / UNIT) + pm_heavy_row_entries(G, cap); }
 
 template <int NFFT>
 static hipError_t deposit_dispatch(pm_ctx *c)
 {
     const int G = c->g.G;
-    const uint32_t R = (uint32_t)c->g.Gd * (uint32_t)G;
-    hipError_t e = hipMemsetAsync(c->counters, 0, sizeof(unsigned long long), c->stream);
+    const uint32_t R = (uint32_t)c->g.Gd * (uint32_t)G, Rs = (uint32_t)c->g.Gs * (uint32_t)G;
+    hipError_t e = hipMemsetAsync(c->counters, 0, 64 * sizeof(uint32_t), c->stream);
     if (e != hipSuccess) return e;
+    k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, c->counters);
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
     k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
-        c->frac, c->key_out, c->row_start, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->g);
-    k_deposit_units<<<PM_UNIT_GRID, BLOCK, lds_rows, c->stream>>>(c->frac, c->key_out, c->row_start, c->heavy_rows, c->counters, c->unit_rows, c->g);
-    k_sum_units<NFFT><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->heavy_rows, c->counters, c->unit_rows, c->density,
-                                                                        c->spectrum, c->twiddle, c->g);
+        c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->light_rows, c->g);
+    const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);
+    static bool attr[64] = {};                          // per device
+    if (lds_units > 64 * 1024 && !attr[c->device & 63]) {
+        e = hipFuncSetAttribute((const void *)k_deposit_units, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_units);
+        if (e != hipSuccess) return e;
+        attr[c->device & 63] = true;
+    }
+    k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, c->stream>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, c->counters,
+                                                                         c->unit_rows, c->g);
+    k_sum_units<NFFT><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, c->counters, c->unit_rows,
+                                                                                        c->light_rows, c->density, c->spectrum, c->twiddle, c->g);
     return hipGetLastError();
 }
 
