@@ -127,6 +127,11 @@ static int create_impl(pm_ctx *c)
     const size_t plane = (size_t)G * G, planes = (size_t)c->g.Gs;    // a slab context holds its own planes only
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(c, hipHostMalloc((void **)&c->units_seen, sizeof(uint32_t), hipHostMallocDefault));
+    *c->units_seen = 1;
     for (int s = 0; s < PM_NSTAGES; ++s)
         for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
 
@@ -243,6 +248,10 @@ void pm_destroy(pm_ctx *c)
     for (int s = 0; s < PM_NSTAGES; ++s)
         for (int k = 0; k < 2; ++k)
             if (c->ev[s][k]) hipEventDestroy(c->ev[s][k]);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->units_seen) hipHostFree((void *)c->units_seen);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

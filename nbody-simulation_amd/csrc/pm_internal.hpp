@@ -49,6 +49,9 @@ struct pm_ctx {
     int64_t cap = 0;    // particle capacity
     int64_t n = 0;      // particles held
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;         // a second stream: the units of crowded rows are summed beside the ordinary rows
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    volatile uint32_t *units_seen = nullptr;    // pinned host word: how many units a recent deposit planned (copied back without waiting)
     bool own_stream = true;     // false after pm_set_stream: the caller's stream, which orders this context's work with the caller's
 
     // Particle state, double-buffered: `cur` is the live set, 1-cur the target of the next

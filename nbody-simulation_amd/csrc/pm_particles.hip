@@ -990,8 +990,6 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, c->counters);
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
-    k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
-        c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->light_rows, c->g);
     const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);
     static bool attr[64] = {};                          // per device
     if (lds_units > 64 * 1024 && !attr[c->device & 63]) {
@@ -999,8 +997,22 @@ static hipError_t deposit_dispatch(pm_ctx *c)
         if (e != hipSuccess) return e;
         attr[c->device & 63] = true;
     }
-    k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, c->stream>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, c->counters,
-                                                                         c->unit_rows, c->g);
+    // The units need the plan only: they are summed on the side stream while the rows are walked on this one --
+    // unless recent deposits had no units at all (the count comes back to the host without anyone waiting for
+    // it, so it is a step or two old: good enough to decide where to launch a kernel that finds out for itself).
+    const bool beside = *c->units_seen != 0;
+    if ((e = hipMemcpyAsync((void *)c->units_seen, c->counters + COUNTER_UNITS, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+    hipStream_t us = beside ? c->side : c->stream;
+    if (beside) {
+        if ((e = hipEventRecord(c->ev_fork, c->stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
+    }
+    k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, c->counters,
+                                                                  c->unit_rows, c->g);
+    if (beside && (e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
+    k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
+        c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->light_rows, c->g);
+    if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
     k_sum_units<NFFT><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, c->counters, c->unit_rows,
                                                                                         c->light_rows, c->density, c->spectrum, c->twiddle, c->g);
     return hipGetLastError();
