@@ -1,0 +1,14 @@
+#!/bin/bash
+# build_variant.sh NAME [extra hipcc flags]: a tuning build of the library into nbody-simulation_amd/lib/var/NAME.so
+set -e
+cd "$(dirname "$0")/../nbody-simulation_amd"
+name=$1; shift
+tmp=$(mktemp -d)
+mkdir -p lib/var
+for f in pm_api pm_diag pm_fft pm_mesh pm_particles pm_slab pm_sort; do
+  c=-ffp-contract=off; [ $f = pm_fft ] && c=-ffp-contract=fast
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $c -I../include -Icsrc -Wno-unused-result -Wno-unused-value "$@" -c csrc/$f.hip -o $tmp/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o lib/var/$name.so $tmp/*.o -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
+rm -rf $tmp
