@@ -21,6 +21,7 @@
 #ifndef PM_H
 #define PM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -80,6 +81,19 @@ int pm_forces(pm_ctx *ctx);
 int pm_gather_kick_drift(pm_ctx *ctx, double dt);
 /* nsteps passes of the loop body main.py:50-60 with all state resident. */
 int pm_step(pm_ctx *ctx, double dt, int nsteps);
+/* The whole main loop main.py:44-67: nsteps passes of the loop body, and after each of them
+ *  - trajectory.append(positions.copy()) (main.py:36, 61): if trajectory is not NULL, the positions after step s, in
+ *    the caller's original order, go to trajectory[s] of a host array (nsteps, n, 3) float32.  The copy of step s
+ *    runs on a stream of its own beside step s + 1 (two snapshot buffers on the device), which hides it when the host
+ *    array is page-locked (pm_host_alloc); into pageable memory the copies are correct but the host waits for each;
+ *  - every energy_every-th step (step % energy_every == 0, main.py:64; 0 = never): KE and PE as pm_energies computes
+ *    them go to ke[step / energy_every], pe[step / energy_every] (arrays of (nsteps - 1) / energy_every + 1 doubles).
+ * Returns when everything has arrived. */
+int pm_run(pm_ctx *ctx, double dt, int nsteps, float *trajectory, int energy_every, double *ke, double *pe);
+/* Page-locked host memory for pm_run's trajectory (hipHostMalloc / hipHostFree).  No counterpart in the reference,
+ * whose trajectory is a list of NumPy arrays; NULL on failure (message via pm_last_error(NULL)). */
+void *pm_host_alloc(size_t bytes);
+void pm_host_free(void *p);
 
 /* Particle state in the caller's original order.  pos is written as float32
  * (n,3) once a drift has happened, in the dtype given to pm_set_particles

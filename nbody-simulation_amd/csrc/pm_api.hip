@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -252,6 +253,12 @@ void pm_destroy(pm_ctx *c)
     if (c->units_seen) hipHostFree((void *)c->units_seen);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->copy) { hipStreamSynchronize(c->copy); hipStreamDestroy(c->copy); }
+    for (int b = 0; b < 2; ++b) {
+        hipFree(c->snap[b]);
+        if (c->snap_ready[b]) hipEventDestroy(c->snap_ready[b]);
+        if (c->snap_done[b]) hipEventDestroy(c->snap_done[b]);
+    }
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -435,6 +442,78 @@ int pm_step(pm_ctx *c, double dt, int nsteps)
         TRY(gather_kick_drift(c, dt, fused));
     }
     return PM_OK;
+}
+
+// main.py:44-67 with the trajectory copies beside the steps
+int pm_run(pm_ctx *c, double dt, int nsteps, float *trajectory, int energy_every, double *ke, double *pe)
+{
+    TRY(whole_mesh(c));
+    TRY(need_particles(c));
+    if (nsteps < 0 || energy_every < 0) return fail(c, PM_EINVAL, "nsteps < 0 or energy_every < 0");
+    if (nsteps == 0) return PM_OK;
+    if (energy_every > 0 && (!ke || !pe)) return fail(c, PM_EINVAL, "energy_every > 0 needs ke and pe");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n, snap_bytes = n * 3 * sizeof(float);
+    const int nsamples = energy_every > 0 ? (nsteps - 1) / energy_every + 1 : 0;
+    if (trajectory && n) {
+        if (!c->copy) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            if (!c->snap[b]) HIP_TRY(c, hipMalloc((void **)&c->snap[b], (size_t)c->cap * 3 * sizeof(float)));
+            if (!c->snap_ready[b]) HIP_TRY(c, hipEventCreateWithFlags(&c->snap_ready[b], hipEventDisableTiming));
+            if (!c->snap_done[b]) HIP_TRY(c, hipEventCreateWithFlags(&c->snap_done[b], hipEventDisableTiming));
+        }
+    }
+    double *elog = nullptr;                 // (nsamples, 2) on the device
+    if (nsamples) HIP_TRY(c, hipMalloc((void **)&elog, (size_t)nsamples * 2 * sizeof(double)));
+    int rc = PM_OK;
+    for (int s = 0; s < nsteps && rc == PM_OK; ++s) {
+        rc = pm_step(c, dt, 1);
+        if (rc != PM_OK) break;
+        if (trajectory && n) {
+            const int b = s & 1;
+            hipError_t e = hipSuccess;
+            // the copy that read this buffer two steps ago must have finished
+            if (s >= 2) e = hipStreamWaitEvent(c->stream, c->snap_done[b], 0);
+            // main.py:60: positions are float32 from the first drift on
+            if (e == hipSuccess) e = pm_launch_export_particles(c, c->snap[b], nullptr);
+            if (e == hipSuccess) e = hipEventRecord(c->snap_ready[b], c->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->copy, c->snap_ready[b], 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(trajectory + (size_t)s * n * 3, c->snap[b], snap_bytes, hipMemcpyDeviceToHost, c->copy);
+            if (e == hipSuccess) e = hipEventRecord(c->snap_done[b], c->copy);
+            if (e != hipSuccess) { rc = fail(c, PM_EHIP, hipGetErrorString(e)); break; }
+        }
+        if (nsamples && s % energy_every == 0) {
+            const int k = s / energy_every;
+            hipError_t e = pm_launch_energies(c, elog + 2 * k, elog + 2 * k + 1);
+            if (e != hipSuccess) { rc = fail(c, PM_EHIP, hipGetErrorString(e)); break; }
+        }
+    }
+    // everything queued so far is drained also after an error: the caller's arrays must not be written to later
+    hipError_t e1 = c->copy ? hipStreamSynchronize(c->copy) : hipSuccess;
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    if (rc == PM_OK && nsamples) {
+        std::vector<double> host((size_t)nsamples * 2);
+        hipError_t e = hipMemcpy(host.data(), elog, host.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, PM_EHIP, hipGetErrorString(e));
+        else for (int k = 0; k < nsamples; ++k) { ke[k] = host[2 * k]; pe[k] = host[2 * k + 1]; }
+    }
+    if (elog) hipFree(elog);
+    if (rc == PM_OK && e1 != hipSuccess) rc = fail(c, PM_EHIP, hipGetErrorString(e1));
+    if (rc == PM_OK && e2 != hipSuccess) rc = fail(c, PM_EHIP, hipGetErrorString(e2));
+    return rc;
+}
+
+void *pm_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { pm_set_create_error(std::string("pm_host_alloc: ") + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+void pm_host_free(void *p)
+{
+    if (p) hipHostFree(p);
 }
 
 int pm_get_particles(pm_ctx *c, void *pos, int *pos_dtype, void *vel, int *vel_dtype)

@@ -45,6 +45,10 @@ template <> struct alignas(16) pm_vrec<double> { double x, y, z; uint32_t id; ui
 struct pm_ctx {
     pm_geom g{};
     int device = 0;
+    // pm_run: snapshot buffers (positions in the caller's order), the stream their copies to the host run on
+    float *snap[2] = {nullptr, nullptr};
+    hipStream_t copy = nullptr;
+    hipEvent_t snap_ready[2] = {nullptr, nullptr}, snap_done[2] = {nullptr, nullptr};
     unsigned flags = 0;
     int64_t cap = 0;    // particle capacity
     int64_t n = 0;      // particles held

@@ -30,6 +30,9 @@ SIGNATURES = {
     "pm_forces": (_int, [_c_p]),
     "pm_gather_kick_drift": (_int, [_c_p, _dbl]),
     "pm_step": (_int, [_c_p, _dbl, _int]),
+    "pm_run": (_int, [_c_p, _dbl, _int, _c_p, _int, _c_p, _c_p]),
+    "pm_host_alloc": (_c_p, [ctypes.c_size_t]),
+    "pm_host_free": (None, [_c_p]),
     "pm_get_particles": (_int, [_c_p, _c_p, ctypes.POINTER(_int), _c_p, ctypes.POINTER(_int)]),
     "pm_get_forces": (_int, [_c_p, _c_p]),
     "pm_get_mesh": (_int, [_c_p, _int, _c_p]),
@@ -92,6 +95,32 @@ def check(ctx, rc):
         if rc == PM_ERANGE:
             raise IndexError(text)          # what the reference's NumPy indexing raises
         raise PMError(text)
+
+
+class _PinnedBlock:
+    """Owner of one pm_host_alloc allocation; freed when the last array over it is gone."""
+
+    def __init__(self, nbytes):
+        self.lib = load()
+        self.address = self.lib.pm_host_alloc(nbytes)
+        if not self.address:
+            raise MemoryError(f"pm_host_alloc({nbytes}): " + self.lib.pm_last_error(None).decode())
+
+    def __del__(self):
+        if getattr(self, "address", None):
+            self.lib.pm_host_free(self.address)
+            self.address = None
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """np.empty in page-locked host memory (pm_host_alloc): copies from the device into it run beside kernels.
+    The memory lives as long as the array or any view of it."""
+    dtype = np.dtype(dtype)
+    nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
+    block = _PinnedBlock(nbytes)
+    buf = (ctypes.c_char * nbytes).from_address(block.address)
+    buf._block = block                      # the ctypes object is the base of every array made from it
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def ptr(a):

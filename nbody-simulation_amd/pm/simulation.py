@@ -76,6 +76,23 @@ class Simulation:
     def step(self, dt, n=1):
         self._ck(self.lib.pm_step(self.ctx, float(dt), int(n)))
 
+    def run(self, steps, dt, trajectory=True, energy_every=10, pinned=True):
+        """The main loop of the reference (main.py:44-67): `steps` steps; returns (trajectory, energies) where
+        trajectory[s] is `positions.copy()` after step s (main.py:61; an array (steps, N, 3) float32 instead of a
+        list, None if trajectory is False) and energies is the array of [KE, PE, KE + PE] rows of main.py:64-67, 72
+        (one per energy_every-th step; empty if energy_every is 0).  The snapshot of a step is copied to the host
+        while the next step runs; pinned=False keeps the trajectory in ordinary pageable memory."""
+        steps, energy_every = int(steps), int(energy_every)
+        n = self.n
+        traj = None
+        if trajectory:
+            traj = L.pinned_empty((steps, n, 3), np.float32) if pinned else np.empty((steps, n, 3), np.float32)
+        ns = (steps - 1) // energy_every + 1 if energy_every > 0 and steps > 0 else 0
+        ke, pe = np.zeros(ns, np.float64), np.zeros(ns, np.float64)
+        self._ck(self.lib.pm_run(self.ctx, float(dt), steps, L.ptr(traj), energy_every,
+                                 L.ptr(ke) if ns else None, L.ptr(pe) if ns else None))
+        return traj, np.stack((ke, pe, ke + pe), axis=1)
+
     def energies(self):
         """(KE, PE) of functions.py:352-361 on the live state and the held potential mesh."""
         ke, pe = L._dbl(), L._dbl()

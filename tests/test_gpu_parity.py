@@ -437,6 +437,42 @@ def test_energies(pm, golden):
     F.release()
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_run_is_the_main_loop(pm, golden, pinned):
+    """Simulation.run (pm_run) = main.py:44-67: trajectory[s] is positions.copy() after step s, energies every
+    energy_every-th step.  Bitwise equal to stepping and downloading by hand; the golden vectors pin the values."""
+    for name in ("uniform_n10000_g32.npz", "c1mini_g50.npz"):
+        g = golden(name)
+        G, L, dt = int(g["G"]), int(g["L"]), float(g["dt"])
+        K = 12
+        with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"]) as sim:
+            traj, en = sim.run(K, dt, trajectory=True, energy_every=5, pinned=pinned)
+            v_end = sim.velocities()
+        assert traj.shape == (K, len(g["mass"]), 3) and traj.dtype == np.float32
+        assert en.shape == (3, 3) and np.array_equal(en[:, 2], en[:, 0] + en[:, 1])
+        with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"]) as ref:
+            for s in range(K):
+                ref.step(dt)
+                assert np.array_equal(traj[s], ref.positions()), (name, s)
+                if s % 5 == 0:
+                    assert en[s // 5, :2].tolist() == list(ref.energies()), (name, s)
+            assert np.array_equal(v_end, ref.velocities())
+        for s in (1, 5, 10):
+            assert np.abs(traj[s - 1].astype(np.float64) - g[f"x{s}"]).max() <= 1e-5 * L, (name, s)
+        assert abs(en[0, 0] - g["s0_KE"]) <= 1e-5 * abs(g["s0_KE"]) and abs(en[0, 1] - g["s0_PE"]) <= 1e-5 * abs(g["s0_PE"])
+    # views keep the page-locked block alive; no trajectory, no energies, no steps
+    g = golden("uniform_n10000_g32.npz")
+    with pm.Simulation(int(g["G"]), int(g["L"]), g["pos0"], g["vel0"], g["mass"]) as sim:
+        last = sim.run(3, float(g["dt"]), energy_every=0, pinned=pinned)[0][-1]
+        none, en = sim.run(2, float(g["dt"]), trajectory=False, energy_every=1)
+        assert none is None and en.shape == (2, 3)
+        traj, en = sim.run(0, float(g["dt"]))
+        assert traj.shape == (0, 10000, 3) and en.shape == (0, 3)
+    import gc
+    gc.collect()
+    assert np.isfinite(last).all() and last.shape == (10000, 3)
+
+
 def test_ngp_variants(pm, golden):
     from pm import functions as F
     g = golden("uniform_n10000_g32.npz")
