@@ -65,17 +65,24 @@ struct col_pass {
 #ifndef PM_EPT_INV
 #define PM_EPT_INV 8
 #endif
+// columns per workgroup: 16 (128-byte row segments), or 8 for the x pass at N = 1024 (64-byte segments, but half the
+// LDS, so that a CU holds two workgroups and one's butterflies run beside the other's loads: -10 % for that pass; the y
+// passes and N = 512, whose tiles leave room for two workgroups anyway, are faster with 16)
+#ifndef PM_COLS_GREEN_1024
+#define PM_COLS_GREEN_1024 8
+#endif
 template <int N, int DIR, bool GREEN> struct col_plan {
+    static constexpr int C = (N == 1024 && GREEN) ? PM_COLS_GREEN_1024 : 16;
     static constexpr int EPT = N != 512 ? 16 : GREEN ? PM_EPT_GREEN : DIR < 0 ? PM_EPT_FWD : PM_EPT_INV;
     static constexpr int R1 = N / 64;                   // first radix
     static constexpr int TPC = N / EPT;                 // threads per column
-    static constexpr int THREADS = COLS * TPC;
+    static constexpr int THREADS = C * TPC;
     static constexpr int NB1 = (N / R1) / TPC;          // butterflies per thread in stage 1
     static constexpr int NB = (N / 8) / TPC;            // ... in stages 2 and 3 (= 4)
-    static constexpr size_t LDS_BYTES = (size_t)(N * COLS + N) * sizeof(float2);
+    static constexpr size_t LDS_BYTES = (size_t)(N * C + N) * sizeof(float2);
 };
 
-// Thread t owns column c = t & 15; jl = t >> 4 is its place among the column's threads.  Stage 1
+// Thread t owns column c = t % C of its workgroup's C columns; jl = t / C is its place among the column's threads.  Stage 1
 // (radix R1, no twiddles) takes butterflies j = jl + TPC b and rows j + 64 r; stages 2 and 3 (radix 8)
 // take j = jl + TPC b and rows j + (N/8) r.  After stage 3 the thread holds the rows jl + TPC m, m < EPT:
 // exactly the inputs of its stage-1 butterflies, which is what lets the Green pass turn round in registers.
@@ -85,13 +92,19 @@ __global__ void __launch_bounds__((col_plan<N, DIR, GREEN>::THREADS))
 k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 {
     using plan = col_plan<N, DIR, GREEN>;
-    constexpr int R1 = plan::R1, TPC = plan::TPC, NB1 = plan::NB1, NB = plan::NB, Q = N / 8;
-    extern __shared__ float2 lds[];                 // [N][COLS] tile, then the N twiddles
+    constexpr int C = plan::C, R1 = plan::R1, TPC = plan::TPC, NB1 = plan::NB1, NB = plan::NB, Q = N / 8;
+    extern __shared__ float2 lds[];                 // [N][C] tile, then the N twiddles
     float2 *tile = lds;
-    float2 *tw = lds + N * COLS;
-    const int t = threadIdx.x, c = t & (COLS - 1), jl = t >> 4;
-    const int outer = blockIdx.x / p.ntiles, ct = p.tile0 + blockIdx.x % p.ntiles;
-    const int col = ct * COLS + c;
+    float2 *tw = lds + N * C;
+    const int t = threadIdx.x, c = t & (C - 1), jl = t / C;
+    // S = 16 / C workgroups share a 16-column tile.  The hardware hands workgroup b to XCD b % 8: the two halves of a
+    // tile are given to workgroups b and b + 8, so that the 128-byte lines they share are fetched into one L2.
+    constexpr int S = COLS / C;
+    int lb = blockIdx.x;
+    if (S == 2 && (lb | 15) < (int)gridDim.x) lb = (lb & ~15) + 2 * (lb & 7) + ((lb >> 3) & 1);
+    const int per_outer = p.ntiles * S;
+    const int outer = lb / per_outer, sub = lb % per_outer;
+    const int col = p.tile0 * COLS + sub * C + c;
     const bool valid = col < p.ncols;
     float2 *g = p.spec + (int64_t)outer * p.outer_stride + col;
     // the same column in the all-to-all buffer: plane `outer`'s rows of block b start at (b * Gs + outer) * Gs * pitch
@@ -121,7 +134,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
             fft_r<R1, D>(v + b * R1);
             int j = jl + TPC * b;
 #pragma unroll
-            for (int r = 0; r < R1; ++r) tile[(R1 * j + r) * COLS + c] = v[b * R1 + r];
+            for (int r = 0; r < R1; ++r) tile[(R1 * j + r) * C + c] = v[b * R1 + r];
         }
     };
     auto stage2 = [&](auto dir) {
@@ -129,7 +142,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[b * 8 + r] = tile[(jl + TPC * b + Q * r) * COLS + c];
+            for (int r = 0; r < 8; ++r) v[b * 8 + r] = tile[(jl + TPC * b + Q * r) * C + c];
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -139,7 +152,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
             fft8<D>(v + b * 8);
             int j0 = (j / R1) * (R1 * 8) + k;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) tile[(j0 + R1 * r) * COLS + c] = v[b * 8 + r];
+            for (int r = 0; r < 8; ++r) tile[(j0 + R1 * r) * C + c] = v[b * 8 + r];
         }
     };
     auto stage3 = [&](auto dir) {
@@ -147,7 +160,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[b * 8 + r] = tile[(jl + TPC * b + Q * r) * COLS + c];
+            for (int r = 0; r < 8; ++r) v[b * 8 + r] = tile[(jl + TPC * b + Q * r) * C + c];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             int j = jl + TPC * b;
@@ -286,7 +299,7 @@ hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
         if (e != hipSuccess) return e;
         attr[dev] = true;
     }
-    k_col_fft<N, DIR, GREEN, BLK><<<blocks, col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(p, c->twiddle);
+    k_col_fft<N, DIR, GREEN, BLK><<<blocks * (COLS / col_plan<N, DIR, GREEN>::C), col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(p, c->twiddle);
     return hipGetLastError();
 }
 

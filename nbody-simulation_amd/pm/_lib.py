@@ -2,6 +2,7 @@
 library or a failing call raises."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -77,6 +78,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise PMError(f"{LIB_PATH} is missing: build it with `make -C nbody-simulation_amd` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
+        # PyTorch ships a HIP runtime of its own, and the first one loaded serves the whole process: torch does not
+        # find the GPU behind the system's runtime, while this library works on either.  So where torch is installed
+        # it is imported first (PM_NO_TORCH=1 skips that for processes that never use torch).
+        if "torch" not in sys.modules and not os.environ.get("PM_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
