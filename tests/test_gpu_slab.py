@@ -27,7 +27,8 @@ def make(n, L, seed, crowd):
 
 
 CASES = {"g32": dict(G=32, L=100, n=20000, dt=0.002, K=5, crowd=0.48),        # rocFFT plans
-         "g512": dict(G=512, L=10000, n=200000, dt=0.0005, K=3, crowd=0.49)}    # hand-written transforms
+         "g512": dict(G=512, L=10000, n=200000, dt=0.0005, K=3, crowd=0.49),    # hand-written transforms
+         "g1024": dict(G=1024, L=10000, n=200000, dt=0.0005, K=2, crowd=0.49)}  # ... with 8-column tiles along x
 
 
 def single_context(case):
@@ -83,7 +84,7 @@ def test_slab_world1_gpu(case, tmp_path):
     check(case, [out])
 
 
-@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("case", ["g32", "g512"])
 def test_slab_world2_one_gpu(case, tmp_path):
     import torch.multiprocessing as mp
     with socket.socket() as s:
