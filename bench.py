@@ -279,7 +279,7 @@ def slab_probe(args, rank, world, dist):
         if r.returncode == 0 and (lines or rank != 0):
             res = json.loads(lines[-1]) if lines else None
             if res is not None:
-                res = {k: res[k] for k in ("value", "unit", "ms_per_step", "scaling", "config")}
+                res = {k: res[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "phases_ms")}
         else:
             res = {"error": f"exit code {r.returncode}: " + r.stderr[-400:]}
     except subprocess.TimeoutExpired:
@@ -312,6 +312,16 @@ def slab_main(args, rank, world, local_rank):
     sim.step(DT, args.steps)
     sim.synchronize()
     elapsed = time.perf_counter() - t0
+    # where the time goes: a few more steps with a mark after every phase (largest value over the ranks)
+    sim.profile = True
+    k_prof = max(1, min(args.steps, 5))
+    sim.step(DT, k_prof)
+    phases = sim.phase_times()
+    sim.profile = False
+    pt = torch.tensor([phases[p] / k_prof for p in sim.PHASES], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+    phases = {p: round(float(v), 4) for p, v in zip(sim.PHASES, pt)}
     loads = [n_local]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -331,6 +341,7 @@ def slab_main(args, rank, world, local_rank):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {G // world} planes",
                        "particles_per_slab_at_start": loads},
+            "phases_ms": phases,
             "roofline": {"bound": "hbm", "kernel": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None, "algorithmic_bytes_per_launch": b_step,
                          "ms_per_launch": ms_step}}), flush=True)

@@ -15,6 +15,7 @@ on device buffers held as torch tensors; the exchanges are torch.distributed col
 anything with the methods of HipSlabEngine; the tests drive the same exchange code with a CPU engine.
 """
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -205,6 +206,34 @@ class SlabSimulation:
         self.engine = engine if engine is not None else HipSlabEngine(self.G, self.L, rank * self.Gs, self.Gs, cap, device_index)
         self.engine.set_particles(positions, velocities, masses, ids)
         self.next, self.prev = (rank + 1) % world, (rank - 1) % world
+        # profile = True: _step marks the end of each phase (events on torch's current stream for a GPU engine, whose
+        # work and collectives all pass through that stream; the host clock otherwise); phase_times() adds them up
+        self.profile = False
+        self._marks = []
+        self._on_gpu = isinstance(self.engine, HipSlabEngine)
+
+    PHASES = ("deposit", "density_halo", "fft_zy", "transpose", "solve_x", "transpose_back", "ifft_yz", "potential_halo",
+              "gather_kick_drift", "migration")
+
+    def _mark(self, name):
+        if self.profile:
+            if self._on_gpu:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+            else:
+                ev = time.perf_counter()
+            self._marks.append((name, ev))
+
+    def phase_times(self):
+        """{phase: milliseconds} summed over the steps made with profile = True since the last call."""
+        if self._on_gpu:
+            torch.cuda.synchronize()
+        out = dict.fromkeys(self.PHASES, 0.0)
+        for (_, a), (name, b) in zip(self._marks, self._marks[1:]):
+            if name != "start":
+                out[name] += a.elapsed_time(b) if self._on_gpu else (b - a) * 1e3
+        self._marks = []
+        return out
 
     def close(self):
         self.engine.close()
@@ -240,28 +269,39 @@ class SlabSimulation:
     def _step(self, dt):
         e, G, Gs, world = self.engine, self.G, self.Gs, self.comm.world
         plane = G * G
+        mark = self._mark
+        mark("start")
         # deposit; the plane beyond the slab belongs to the next rank (functions.py:56: i1 = (i + 1) % G)
         e.deposit()
+        mark("deposit")
         ghost = e.planes_out(0, Gs, 1)
         from_prev, _ = self._neighbours(ghost, ghost.new_empty(0), plane, 0)
         e.planes_in(0, 0, from_prev.reshape(1, G, G), add=True)
+        mark("density_halo")
         # compute_potential (functions.py:73-89)
         e.fft2(-1)
         blocks = e.pack()
         spec_t = e.transposed_buffer()
+        mark("fft_zy")
         self.comm.all_to_all_equal(blocks.reshape(-1), spec_t.reshape(-1))
+        mark("transpose")
         e.solve_x(spec_t)
+        mark("solve_x")
         self.comm.all_to_all_equal(spec_t.reshape(-1), blocks.reshape(-1))
+        mark("transpose_back")
         e.unpack(blocks)
         e.fft2(+1)
+        mark("ifft_yz")
         # potential planes beside the slab: one below (from the previous rank), two above (from the next rank)
         to_next = e.planes_out(1, Gs, 1)            # my last owned plane
         to_prev = e.planes_out(1, 1, 2)             # my first two owned planes
         below, above = self._neighbours(to_next, to_prev, plane, 2 * plane)
         e.planes_in(1, 0, below.reshape(1, G, G))
         e.planes_in(1, Gs + 1, above.reshape(2, G, G))
+        mark("potential_halo")
         # gradient, gather, kick, drift (main.py:54-60); then the particles that changed slab
         e.gather_kick_drift(dt)
+        mark("gather_kick_drift")
         counts, records = e.outbox()
         flat = records.reshape(-1)
         c = torch.tensor(counts, dtype=torch.int64)
@@ -271,6 +311,7 @@ class SlabSimulation:
         got = self.comm.all_to_all([flat[offs[p]:offs[p + 1]] for p in range(world)], [8 * k for k in incoming])
         arrivals = torch.cat(got).reshape(-1, 8)
         e.inbox(arrivals)
+        mark("migration")
 
     def particles(self):
         """(ids, positions, velocities) of the particles this rank owns now."""

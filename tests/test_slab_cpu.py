@@ -51,11 +51,15 @@ def run_rank(rank, world, port, out):
     ids = np.arange(N, dtype=np.uint32)
     eng = OracleSlabEngine(G, L, rank * (G // world), G // world)
     sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids[mine], engine=eng)
+    sim.profile = True                       # marks after every phase must not change anything
     moved = 0
     for _ in range(K):
         before = set(sim.particles()[0].tolist())
         sim.step(DT)
         moved += len(before - set(sim.particles()[0].tolist()))
+    phases = sim.phase_times()
+    assert set(phases) == set(sim.PHASES) and all(v >= 0.0 for v in phases.values()) and phases["deposit"] > 0.0
+    assert sim.phase_times() == dict.fromkeys(sim.PHASES, 0.0)
     i, x, v = sim.particles()
     np.savez(out, ids=i, pos=x, vel=v, moved=moved)
     if world > 1:
