@@ -116,9 +116,12 @@ class _PinnedBlock:
             raise MemoryError(f"pm_host_alloc({nbytes}): " + self.lib.pm_last_error(None).decode())
 
     def __del__(self):
-        if getattr(self, "address", None):
-            self.lib.pm_host_free(self.address)
-            self.address = None
+        address, self.address = getattr(self, "address", None), None
+        if address:
+            try:
+                self.lib.pm_host_free(address)
+            except Exception:       # interpreter shutdown: the library may be gone already, and so is the process's memory
+                pass
 
 
 def pinned_empty(shape, dtype=np.float32):

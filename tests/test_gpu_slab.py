@@ -174,3 +174,27 @@ def test_slab_matches_oracle_world1(tmp_path):
     dx = np.abs(d["pos"] - x[d["ids"]])
     assert np.minimum(dx, c["L"] - dx).max() <= 1e-5 * c["L"]
     assert np.abs(d["vel"] - v[d["ids"]]).max() <= 1e-5 * np.abs(v).max()
+
+
+def test_slab_without_particles_and_with_arrivals_only():
+    """A slab that owns no particle steps like any other (zero density, zero potential), and one that is empty until
+    particles arrive takes them in."""
+    import torch
+    from pm.distributed import HipSlabEngine, SlabSimulation
+    G, L = 32, 100.0
+    none = np.zeros((0, 3), np.float32)
+    with SlabSimulation(G, L, none, none, np.zeros(0, np.float32), np.zeros(0, np.uint32), device_index=0, capacity=64) as sim:
+        sim.step(0.01, 2)
+        ids, x, v = sim.particles()
+        assert len(ids) == 0 and x.shape == (0, 3) and v.shape == (0, 3)
+        e = sim.engine
+        assert isinstance(e, HipSlabEngine)
+        # three particles arrive (records of 8 floats: x y z m vx vy vz id-bits)
+        rec = np.zeros((3, 8), np.float32)
+        rec[:, 0:3] = [[10.0, 20.0, 30.0], [55.5, 1.0, 99.0], [99.9, 50.0, 0.1]]
+        rec[:, 3] = 2.0
+        rec[:, 7] = np.array([7, 8, 9], np.uint32).view(np.float32)
+        e.inbox(torch.from_numpy(rec))
+        sim.step(0.01, 1)
+        ids, x, v = sim.particles()
+        assert sorted(ids.tolist()) == [7, 8, 9] and np.isfinite(x).all() and np.isfinite(v).all()
