@@ -45,6 +45,8 @@ enum {
     PM_FLAG_FUSED_GRADIENT = 2u, /* pm_step keeps intermediate meshes on chip where it can: the potential is differenced
                                     inside the gather (no gx,gy,gz), and at grid_size 512 the deposit emits each density
                                     row already transformed along z (no density mesh) */
+    PM_FLAG_NGP = 8u,         /* pm_create only: pm_step runs the nearest-grid-point branch (CIC_interpolation = False,
+                                 main.py:9, 40-41), whose meshes and forces are float64 */
     PM_FLAG_ROCFFT_ONLY = 4u  /* pm_create only: 3-D rocFFT plans for every grid size (no hand-written column FFT) */
 };
 
@@ -126,6 +128,18 @@ int pm_energies(pm_ctx *ctx, double *ke, double *pe);
 int pm_deposit_ngp(pm_ctx *ctx);
 int pm_forces_ngp(pm_ctx *ctx);
 int pm_get_mesh_f64(pm_ctx *ctx, int which, double *out /* G*G*G */);
+/* The rest of that branch in float64, as NumPy runs it on NGP's float64 mesh:
+ * pm_potential_f64: compute_potential(density, grid_size), functions.py:73-89, float64 density -> float64 potential;
+ * pm_gradient_f64:  np.gradient(potential), main.py:54, on the float64 potential;
+ * pm_forces_ngp_f64: force_NGP, functions.py:92-97, on the float64 gradient -> (n,3) float64 via pm_get_forces_f64.
+ * pm_get_mesh_f64 / pm_set_mesh_f64 read and write these meshes (any PM_MESH_* selector).  A context created with
+ * PM_FLAG_NGP runs exactly this chain in pm_step / pm_run, with main.py:58-60 behind it, and pm_energies reads its
+ * float64 potential. */
+int pm_potential_f64(pm_ctx *ctx);
+int pm_gradient_f64(pm_ctx *ctx);
+int pm_forces_ngp_f64(pm_ctx *ctx);
+int pm_get_forces_f64(pm_ctx *ctx, double *forces /* (n,3) */);
+int pm_set_mesh_f64(pm_ctx *ctx, int which, const double *in /* G*G*G */);
 
 /*
  * Slab decomposition of the same path over several GPUs.  The reference is a single-process NumPy

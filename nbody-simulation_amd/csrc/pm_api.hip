@@ -239,6 +239,11 @@ void pm_destroy(pm_ctx *c)
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage); hipFree(c->diag); hipFree(c->density64);
+    hipFree(c->potential64); hipFree(c->spectrum64); hipFree(c->forces64); hipFree(c->fft_work64);
+    for (int d = 0; d < 3; ++d) hipFree(c->grad64[d]);
+    if (c->info64) rocfft_execution_info_destroy(c->info64);
+    if (c->fwd64) rocfft_plan_destroy(c->fwd64);
+    if (c->inv64) rocfft_plan_destroy(c->inv64);
     hipFree(c->outbox); hipFree(c->outbox_key); hipFree(c->outbox_key2); hipFree(c->outbox_idx2); hipFree(c->outbox_offsets);
     hipFree(c->outbox_count); hipFree(c->outbox_tmp);
     for (rocfft_plan p : {c->slab_fwd2, c->slab_inv2, c->slab_fwdx, c->slab_invx})
@@ -278,6 +283,7 @@ int pm_set_stream(pm_ctx *c, void *hip_stream)
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
     if (c->info) FFT_TRY(c, rocfft_execution_info_set_stream(c->info, c->stream));
+    if (c->info64) FFT_TRY(c, rocfft_execution_info_set_stream(c->info64, c->stream));
     return PM_OK;
 }
 
@@ -301,7 +307,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     c->pos_in_f64 = c->pos_f64 = (pos_dtype == PM_F64);
     c->vel_f64 = (vel_dtype == PM_F64);
     TRY(alloc_particles(c));
-    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->keys_fresh = false;
+    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false;
     size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
     if (n > 0) {
         // staging: positions (n,3), then the masses behind them
@@ -427,11 +433,17 @@ int pm_gather_kick_drift(pm_ctx *c, double dt)
     return gather_kick_drift(c, dt, false);
 }
 
+static int step_ngp(pm_ctx *c, double dt);
+
 int pm_step(pm_ctx *c, double dt, int nsteps)
 {
     TRY(whole_mesh(c));
     TRY(need_particles(c));
     if (nsteps < 0) return fail(c, PM_EINVAL, "nsteps < 0");
+    if (c->flags & PM_FLAG_NGP) {
+        for (int s = 0; s < nsteps; ++s) TRY(step_ngp(c, dt));
+        return PM_OK;
+    }
     const bool fused = (c->flags & PM_FLAG_FUSED_GRADIENT) != 0;
     for (int s = 0; s < nsteps; ++s) {
         // fused mode on the hand-written FFT path: the deposit leaves z-transformed rows, no density mesh
@@ -654,14 +666,145 @@ int pm_deposit_ngp(pm_ctx *c)
     return PM_OK;
 }
 
+// ---- the NGP branch in float64 ----------------------------------------------------------------------
+
+// meshes, half spectrum and 3-D rocFFT plans in double precision, on first use
+static int ensure_f64(pm_ctx *c)
+{
+    const size_t M = (size_t)c->g.M;
+    const int G = c->g.G;
+    TRY(dalloc(c, &c->density64, M));
+    TRY(dalloc(c, &c->potential64, M));
+    for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad64[d], M));
+    TRY(dalloc(c, &c->spectrum64, (size_t)G * G * c->g.Gh));
+    TRY(dalloc(c, &c->forces64, 3 * (size_t)c->cap));
+    if (!c->fwd64) {
+        const size_t lengths[3] = {(size_t)G, (size_t)G, (size_t)G};
+        FFT_TRY(c, rocfft_plan_create(&c->fwd64, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                      rocfft_precision_double, 3, lengths, 1, nullptr));
+        FFT_TRY(c, rocfft_plan_create(&c->inv64, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                      rocfft_precision_double, 3, lengths, 1, nullptr));
+        size_t wf = 0, wi = 0;
+        FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->fwd64, &wf));
+        FFT_TRY(c, rocfft_plan_get_work_buffer_size(c->inv64, &wi));
+        const size_t work = wf > wi ? wf : wi;
+        FFT_TRY(c, rocfft_execution_info_create(&c->info64));
+        if (work) {
+            HIP_TRY(c, hipMalloc(&c->fft_work64, work));
+            FFT_TRY(c, rocfft_execution_info_set_work_buffer(c->info64, c->fft_work64, work));
+        }
+    }
+    FFT_TRY(c, rocfft_execution_info_set_stream(c->info64, c->stream));
+    return PM_OK;
+}
+
+static double *mesh64_ptr(pm_ctx *c, int which)
+{
+    switch (which) {
+    case PM_MESH_DENSITY: return c->density64;
+    case PM_MESH_POTENTIAL: return c->potential64;
+    case PM_MESH_GX: return c->grad64[0];
+    case PM_MESH_GY: return c->grad64[1];
+    case PM_MESH_GZ: return c->grad64[2];
+    default: return nullptr;
+    }
+}
+
 int pm_get_mesh_f64(pm_ctx *c, int which, double *out)
 {
-    if (!c) return PM_EINVAL;
-    if (which != PM_MESH_DENSITY || !out) return fail(c, PM_EINVAL, "only the NGP density is a float64 mesh");
-    if (!c->density64) return fail(c, PM_ESTATE, "no float64 density: call pm_deposit_ngp first");
+    TRY(whole_mesh(c));
+    double *p = mesh64_ptr(c, which);
+    if (which < PM_MESH_DENSITY || which > PM_MESH_GZ || !out) return fail(c, PM_EINVAL, "bad mesh selector or NULL buffer");
+    if (!p) return fail(c, PM_ESTATE, "no float64 meshes yet: call pm_deposit_ngp or pm_set_mesh_f64 first");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(out, c->density64, (size_t)c->g.M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, p, (size_t)c->g.M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+int pm_set_mesh_f64(pm_ctx *c, int which, const double *in)
+{
+    TRY(whole_mesh(c));
+    if (which < PM_MESH_DENSITY || which > PM_MESH_GZ || !in) return fail(c, PM_EINVAL, "bad mesh selector or NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure_f64(c));
+    HIP_TRY(c, hipMemcpyAsync(mesh64_ptr(c, which), in, (size_t)c->g.M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+// functions.py:73-89 on a float64 density.  The mean that :81-82 subtract only moves the DC term, which :86 zeroes.
+int pm_potential_f64(pm_ctx *c)
+{
+    TRY(whole_mesh(c));
+    if (!c->density64) return fail(c, PM_ESTATE, "no float64 density: call pm_deposit_ngp or pm_set_mesh_f64 first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure_f64(c));
+    {
+        stage_timer t(c, PM_STAGE_FFT_FWD);
+        void *in[1] = {c->density64}, *out[1] = {c->spectrum64};
+        FFT_TRY(c, rocfft_execute(c->fwd64, in, out, c->info64));
+    }
+    {
+        stage_timer t(c, PM_STAGE_GREEN);
+        HIP_TRY(c, pm_launch_green64(c));
+    }
+    {
+        stage_timer t(c, PM_STAGE_FFT_INV);
+        void *in[1] = {c->spectrum64}, *out[1] = {c->potential64};
+        FFT_TRY(c, rocfft_execute(c->inv64, in, out, c->info64));
+    }
+    return PM_OK;
+}
+
+int pm_gradient_f64(pm_ctx *c)
+{
+    TRY(whole_mesh(c));
+    if (!c->potential64) return fail(c, PM_ESTATE, "no float64 potential: call pm_potential_f64 or pm_set_mesh_f64 first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    stage_timer t(c, PM_STAGE_GRADIENT);
+    HIP_TRY(c, pm_launch_gradient64(c));
+    return PM_OK;
+}
+
+int pm_forces_ngp_f64(pm_ctx *c)
+{
+    TRY(whole_mesh(c));
+    TRY(need_particles(c));
+    if (!c->grad64[0]) return fail(c, PM_ESTATE, "no float64 gradient: call pm_gradient_f64 or pm_set_mesh_f64 first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    stage_timer t(c, PM_STAGE_GATHER);
+    HIP_TRY(c, pm_launch_ngp_gather(c, 0.0, false, c->forces64));
+    c->have_forces64 = true;
+    return PM_OK;
+}
+
+int pm_get_forces_f64(pm_ctx *c, double *forces)
+{
+    TRY(whole_mesh(c));
+    TRY(need_particles(c));
+    if (!c->have_forces64) return fail(c, PM_ESTATE, "no float64 forces: call pm_forces_ngp_f64 first");
+    if (!forces) return fail(c, PM_EINVAL, "forces is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n) {
+        // storage order -> the caller's order, through the staging buffer (n * 24 bytes fit its n * 32)
+        HIP_TRY(c, pm_launch_export_forces64(c, (double *)c->stage));
+        HIP_TRY(c, hipMemcpyAsync(forces, c->stage, (size_t)c->n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return PM_OK;
+}
+
+// main.py:50-60 with CIC_interpolation = False
+static int step_ngp(pm_ctx *c, double dt)
+{
+    TRY(pm_deposit_ngp(c));
+    TRY(pm_potential_f64(c));
+    TRY(pm_gradient_f64(c));
+    stage_timer t(c, PM_STAGE_GATHER);
+    HIP_TRY(c, pm_launch_ngp_gather(c, dt, true, nullptr));
+    c->pos_f64 = false;      // positions are float32 from the first drift on (main.py:60)
+    c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false;
     return PM_OK;
 }
 
@@ -669,7 +812,7 @@ int pm_set_flags(pm_ctx *c, unsigned flags)
 {
     if (!c) return PM_EINVAL;
     if (flags & ~(unsigned)(PM_FLAG_TIMING | PM_FLAG_FUSED_GRADIENT)) return fail(c, PM_EINVAL, "only PM_FLAG_TIMING and PM_FLAG_FUSED_GRADIENT can change");
-    flags |= c->flags & PM_FLAG_ROCFFT_ONLY;
+    flags |= c->flags & (PM_FLAG_ROCFFT_ONLY | PM_FLAG_NGP);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < PM_NSTAGES; ++s) stage_timer::flush(c, s);

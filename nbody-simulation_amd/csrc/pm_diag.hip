@@ -69,9 +69,10 @@ k_kinetic(const pm_prec<float> *__restrict__ Pf, const pm_prec<double> *__restri
 }
 
 // PE = 0.5 * sum(m * phi[ngp cell]): float32 product, float64 sum.
-template <typename TP>
+// (with a float64 potential -- the NGP branch -- the product is float64 as well)
+template <typename TP, typename TM>
 __global__ void __launch_bounds__(BLOCK)
-k_potential_energy(const pm_prec<TP> *__restrict__ P, const float *__restrict__ phi, int64_t n, pm_geom g, double *__restrict__ partial)
+k_potential_energy(const pm_prec<TP> *__restrict__ P, const TM *__restrict__ phi, int64_t n, pm_geom g, double *__restrict__ partial)
 {
     const int G = g.G;
     const TP L = (TP)g.L, Gf = (TP)G;
@@ -79,7 +80,7 @@ k_potential_energy(const pm_prec<TP> *__restrict__ P, const float *__restrict__ 
     for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * BLOCK) {
         const pm_prec<TP> p = P[r];
         int i = ngp_wrapped_index<TP>(p.x, L, Gf, G), j = ngp_wrapped_index<TP>(p.y, L, Gf, G), k = ngp_wrapped_index<TP>(p.z, L, Gf, G);
-        acc += (double)(p.m * phi[((int64_t)i * G + j) * G + k]);
+        acc += (double)((TM)p.m * phi[((int64_t)i * G + j) * G + k]);
     }
     block_partial(acc, partial);
 }
@@ -175,6 +176,89 @@ k_ngp_sum(const pm_prec<TP> *__restrict__ P, const uint32_t *__restrict__ key, c
     }
 }
 
+
+// ---- the NGP branch end to end in float64 -----------------------------------------------------------
+// NGP returns a float64 mesh (functions.py:12), so compute_potential (functions.py:73-89) and np.gradient
+// (main.py:54) run in float64 for that branch and force_NGP (functions.py:92-97) returns float64 forces.
+
+// np.fft.fftfreq(G)[a] as float32 (functions.py:75)
+__device__ __forceinline__ float freq32(int a, int G, double invG)
+{
+    int f = (a < (G + 1) / 2) ? a : a - G;
+    return (float)((double)f * invG);
+}
+
+// potential_k = density_k / k2 (functions.py:85): k2 = kx**2 + ky**2 + kz**2 in float32, and NumPy divides a
+// complex128 by it as a multiplication by 1.0 / k2; the 1/M of ifftn (functions.py:89) goes in here too.
+__global__ void k_green64(double2 *__restrict__ S, int G, int Gh, double invM)
+{
+    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= (int64_t)G * G * Gh) return;
+    const int c = (int)(q % Gh), j = (int)((q / Gh) % G), i = (int)(q / ((int64_t)Gh * G));
+    const double invG = 1.0 / (double)G;
+    const float kx = freq32(i, G, invG), ky = freq32(j, G, invG), kz = freq32(c, G, invG);
+    const float k2 = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), __fmul_rn(ky, ky)), __fmul_rn(kz, kz));
+    double2 v = S[q];
+    if ((i | j | c) == 0) v = make_double2(0.0, 0.0);                   // functions.py:86
+    else { const double r = 1.0 / (double)k2; v.x = v.x * r * invM; v.y = v.y * r * invM; }
+    S[q] = v;
+}
+
+// np.gradient(f) in float64: (f[n+1] - f[n-1]) / 2 inside, one-sided differences on the faces
+__global__ void k_gradient64(const double *__restrict__ f, double *__restrict__ gx, double *__restrict__ gy, double *__restrict__ gz, int G)
+{
+    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= (int64_t)G * G * G) return;
+    const int k = (int)(q % G), j = (int)((q / G) % G), i = (int)(q / ((int64_t)G * G));
+    auto d = [&](int a, int64_t stride) {
+        if (a == 0) return f[q + stride] - f[q];
+        if (a == G - 1) return f[q] - f[q - stride];
+        return (f[q + stride] - f[q - stride]) * 0.5;
+    };
+    gx[q] = d(i, (int64_t)G * G); gy[q] = d(j, G); gz[q] = d(k, 1);
+}
+
+// force_NGP on the float64 gradient and, with integrate, main.py:58-60 behind it: `velocities += forces * dt` has
+// a float64 right-hand side (a float32 velocity is widened for the add and rounded once), the drift and the wrap
+// are those of the cloud-in-cell branch.
+template <typename TP, typename TV>
+__global__ void __launch_bounds__(BLOCK)
+k_ngp_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, pm_vrec<TV> *__restrict__ V,
+             const double *__restrict__ gx, const double *__restrict__ gy, const double *__restrict__ gz,
+             double *__restrict__ forces, int64_t n, pm_geom g, double dt, bool integrate)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int G = g.G;
+    const TP L = (TP)g.L, Gf = (TP)G;
+    const pm_prec<TP> p = Pin[r];
+    const int i = ngp_wrapped_index<TP>(p.x, L, Gf, G), j = ngp_wrapped_index<TP>(p.y, L, Gf, G), k = ngp_wrapped_index<TP>(p.z, L, Gf, G);
+    const int64_t q = ((int64_t)i * G + j) * G + k;
+    const double fx = gx[q], fy = gy[q], fz = gz[q];
+    if (forces) { forces[3 * r] = fx; forces[3 * r + 1] = fy; forces[3 * r + 2] = fz; }
+    if (!integrate) return;
+    pm_vrec<TV> v = V[r];
+    v.x = (TV)((double)v.x + fx * dt); v.y = (TV)((double)v.y + fy * dt); v.z = (TV)((double)v.z + fz * dt);
+    V[r] = v;
+    pm_prec<float> o;
+    o.m = p.m;
+    const float Lf = g.Lf;
+    auto wrap = [&](float x) {                       // np.remainder(x, L) in float32: may return exactly L
+        if (x >= 0.0f && x < Lf) return (x == 0.0f) ? 0.0f : x;
+        return np_remainder<float>(x, Lf);
+    };
+    if constexpr (sizeof(TV) == 4 && sizeof(TP) == 4) {
+        const float dtf = (float)dt;
+        o.x = wrap(p.x + v.x * dtf); o.y = wrap(p.y + v.y * dtf); o.z = wrap(p.z + v.z * dtf);
+    } else {
+        double mx, my, mz;
+        if constexpr (sizeof(TV) == 4) { const float dtf = (float)dt; mx = (double)(v.x * dtf); my = (double)(v.y * dtf); mz = (double)(v.z * dtf); }
+        else { mx = v.x * dt; my = v.y * dt; mz = v.z * dt; }
+        o.x = wrap((float)((double)p.x + mx)); o.y = wrap((float)((double)p.y + my)); o.z = wrap((float)((double)p.z + mz));
+    }
+    Pout[r] = o;
+}
+
 }  // namespace
 
 // ke and pe are two doubles in device memory (c->diag + 2*RED_BLOCKS ...); the caller copies them out.
@@ -191,8 +275,13 @@ hipError_t pm_launch_energies(pm_ctx *c, double *d_ke, double *d_pe)
     const pm_prec<double> *pd = c->pos_f64 ? c->pd[u] : nullptr;
     if (c->vel_f64) k_kinetic<double><<<blocks, BLOCK, 0, c->stream>>>(pf, pd, c->vd[c->vcur], vmap, n, part_k);
     else k_kinetic<float><<<blocks, BLOCK, 0, c->stream>>>(pf, pd, c->vf[c->vcur], vmap, n, part_k);
-    if (c->pos_f64) k_potential_energy<double><<<blocks, BLOCK, 0, c->stream>>>(c->pd[u], c->potential, n, c->g, part_p);
-    else k_potential_energy<float><<<blocks, BLOCK, 0, c->stream>>>(c->pf[u], c->potential, n, c->g, part_p);
+    if (c->flags & PM_FLAG_NGP) {
+        if (c->pos_f64) k_potential_energy<double, double><<<blocks, BLOCK, 0, c->stream>>>(c->pd[u], c->potential64, n, c->g, part_p);
+        else k_potential_energy<float, double><<<blocks, BLOCK, 0, c->stream>>>(c->pf[u], c->potential64, n, c->g, part_p);
+    } else {
+        if (c->pos_f64) k_potential_energy<double, float><<<blocks, BLOCK, 0, c->stream>>>(c->pd[u], c->potential, n, c->g, part_p);
+        else k_potential_energy<float, float><<<blocks, BLOCK, 0, c->stream>>>(c->pf[u], c->potential, n, c->g, part_p);
+    }
     k_reduce_final<<<1, 64, 0, c->stream>>>(part_k, blocks, 0.5, d_ke);
     k_reduce_final<<<1, 64, 0, c->stream>>>(part_p, blocks, 0.5, d_pe);
     return hipGetLastError();
@@ -224,5 +313,37 @@ hipError_t pm_launch_ngp_sum(pm_ctx *c)
     const int u = c->cur;
     if (c->pos_f64) k_ngp_sum<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pd[u], c->key_out, c->src, c->n, c->density64);
     else k_ngp_sum<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pf[u], c->key_out, c->src, c->n, c->density64);
+    return hipGetLastError();
+}
+
+// ---- float64 NGP branch: launchers ------------------------------------------------------------------
+
+hipError_t pm_launch_green64(pm_ctx *c)
+{
+    const int G = c->g.G, Gh = c->g.Gh;
+    k_green64<<<grid_for((int64_t)G * G * Gh), BLOCK, 0, c->stream>>>(c->spectrum64, G, Gh, 1.0 / (double)c->g.M);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_gradient64(pm_ctx *c)
+{
+    k_gradient64<<<grid_for(c->g.M), BLOCK, 0, c->stream>>>(c->potential64, c->grad64[0], c->grad64[1], c->grad64[2], c->g.G);
+    return hipGetLastError();
+}
+
+// velocity records must be in storage order (pm_settle_velocities)
+hipError_t pm_launch_ngp_gather(pm_ctx *c, double dt, bool integrate, double *forces)
+{
+    if (c->n == 0) return hipSuccess;
+    const int u = c->cur, v = c->vcur;
+    const dim3 grid = grid_for(c->n);
+    const double *gx = c->grad64[0], *gy = c->grad64[1], *gz = c->grad64[2];
+    if (c->pos_f64) {
+        if (c->vel_f64) k_ngp_gather<double, double><<<grid, BLOCK, 0, c->stream>>>(c->pd[u], c->pf[u], c->vd[v], gx, gy, gz, forces, c->n, c->g, dt, integrate);
+        else k_ngp_gather<double, float><<<grid, BLOCK, 0, c->stream>>>(c->pd[u], c->pf[u], c->vf[v], gx, gy, gz, forces, c->n, c->g, dt, integrate);
+    } else {
+        if (c->vel_f64) k_ngp_gather<float, double><<<grid, BLOCK, 0, c->stream>>>(c->pf[u], c->pf[u], c->vd[v], gx, gy, gz, forces, c->n, c->g, dt, integrate);
+        else k_ngp_gather<float, float><<<grid, BLOCK, 0, c->stream>>>(c->pf[u], c->pf[u], c->vf[v], gx, gy, gz, forces, c->n, c->g, dt, integrate);
+    }
     return hipGetLastError();
 }

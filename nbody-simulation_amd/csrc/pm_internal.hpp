@@ -74,6 +74,7 @@ struct pm_ctx {
     bool vel_f64 = false;
     bool binned = false;        // live set is in cell order and row_start matches it
     bool have_forces = false;
+    bool have_forces64 = false;         // forces64 holds force_NGP of the float64 gradient
     bool keys_fresh = false;    // key_in holds the cell keys of the live positions (written by the last drift)
 
     // binning scratch
@@ -99,6 +100,12 @@ struct pm_ctx {
     size_t fft_work_bytes = 0;
 
     double *density64 = nullptr;        // float64 mesh of the NGP deposit (allocated on first use)
+    // the NGP branch in float64 (allocated on first use): potential, its gradient, the half spectrum, rocFFT plans
+    double *potential64 = nullptr, *grad64[3] = {nullptr, nullptr, nullptr}, *forces64 = nullptr;
+    double2 *spectrum64 = nullptr;
+    rocfft_plan fwd64 = nullptr, inv64 = nullptr;
+    rocfft_execution_info info64 = nullptr;
+    void *fft_work64 = nullptr;
     double *diag = nullptr;             // reduction partials and results of the energy diagnostics
     float *forces = nullptr;            // (n,3) AoS in storage order
     void *stage = nullptr;              // staging for host copies: cap * 32 bytes
@@ -171,8 +178,12 @@ hipError_t pm_launch_gradient(pm_ctx *c);
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);
 hipError_t pm_launch_export_particles(pm_ctx *c, void *pos_aos, void *vel_aos);
 hipError_t pm_launch_export_forces(pm_ctx *c, float *aos);
+hipError_t pm_launch_export_forces64(pm_ctx *c, double *aos);
 hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm);
 hipError_t pm_launch_energies(pm_ctx *c, double *d_ke, double *d_pe);
 hipError_t pm_launch_force_ngp(pm_ctx *c);
 hipError_t pm_launch_ngp_keys(pm_ctx *c, uint32_t *bad);
 hipError_t pm_launch_ngp_sum(pm_ctx *c);
+hipError_t pm_launch_green64(pm_ctx *c);
+hipError_t pm_launch_gradient64(pm_ctx *c);
+hipError_t pm_launch_ngp_gather(pm_ctx *c, double dt, bool integrate, double *forces);

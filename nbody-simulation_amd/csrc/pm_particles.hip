@@ -127,9 +127,9 @@ __global__ void k_export_vel(const pm_vrec<TV> *__restrict__ V, TV *__restrict__
     aos[o] = rec.x; aos[o + 1] = rec.y; aos[o + 2] = rec.z;
 }
 
-template <typename TV>
-__global__ void k_export_forces(const float *__restrict__ in, const pm_vrec<TV> *__restrict__ V, const uint32_t *__restrict__ vmap,
-                                float *__restrict__ out, int64_t n)
+template <typename TV, typename TF = float>
+__global__ void k_export_forces(const TF *__restrict__ in, const pm_vrec<TV> *__restrict__ V, const uint32_t *__restrict__ vmap,
+                                TF *__restrict__ out, int64_t n)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= n) return;
@@ -1090,6 +1090,15 @@ hipError_t pm_launch_export_forces(pm_ctx *c, float *aos)
     const uint32_t *vmap = c->v_stale ? c->src : nullptr;
     if (c->vel_f64) k_export_forces<double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vd[c->vcur], vmap, aos, c->n);
     else k_export_forces<float><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces, c->vf[c->vcur], vmap, aos, c->n);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_export_forces64(pm_ctx *c, double *aos)
+{
+    if (c->n == 0) return hipSuccess;
+    const uint32_t *vmap = c->v_stale ? c->src : nullptr;
+    if (c->vel_f64) k_export_forces<double, double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces64, c->vd[c->vcur], vmap, aos, c->n);
+    else k_export_forces<float, double><<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->forces64, c->vf[c->vcur], vmap, aos, c->n);
     return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PM_LIBRARY") or os.path.join(os.path.dirname(_HERE), 
 
 PM_F32, PM_F64 = 0, 1
 MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ = range(5)
-FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY = 1, 2, 4
+FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP = 1, 2, 4, 8
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
 
 _c_p = ctypes.c_void_p
@@ -43,6 +43,11 @@ SIGNATURES = {
     "pm_deposit_ngp": (_int, [_c_p]),
     "pm_forces_ngp": (_int, [_c_p]),
     "pm_get_mesh_f64": (_int, [_c_p, _int, _c_p]),
+    "pm_set_mesh_f64": (_int, [_c_p, _int, _c_p]),
+    "pm_potential_f64": (_int, [_c_p]),
+    "pm_gradient_f64": (_int, [_c_p]),
+    "pm_forces_ngp_f64": (_int, [_c_p]),
+    "pm_get_forces_f64": (_int, [_c_p, _c_p]),
     "pm_create_slab": (_c_p, [_int, _dbl, _i64, _int, ctypes.c_uint, _int, _int]),
     "pm_slab_set_particles": (_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _i64]),
     "pm_slab_deposit": (_int, [_c_p]),

@@ -23,14 +23,14 @@ __all__ = ["CIC", "NGP", "compute_potential", "gradient", "force_CIC", "force_NG
 _engines = {}
 
 
-def _engine(grid_size, box_size, n):
-    """One cached engine per (grid_size, box_size); regrown when more particles arrive."""
-    key = (int(grid_size), float(box_size))
+def _engine(grid_size, box_size, n, ngp=False):
+    """One cached engine per (grid_size, box_size, branch); regrown when more particles arrive."""
+    key = (int(grid_size), float(box_size), bool(ngp))
     sim = _engines.get(key)
     if sim is None or sim.capacity < n:
         if sim is not None:
             sim.close()
-        sim = _engines[key] = Simulation(grid_size, box_size, capacity=max(n, 1024))
+        sim = _engines[key] = Simulation(grid_size, box_size, capacity=max(n, 1024), interpolation="NGP" if ngp else "CIC")
     return sim
 
 
@@ -50,21 +50,30 @@ def CIC(positions: np.ndarray, grid_size: int, box_size: float, masses: np.ndarr
 
 
 def compute_potential(density: np.ndarray, grid_size: int) -> np.ndarray:
-    """FFT Poisson solve: +density_k / k^2 with k in cycles per sample, DC zeroed -> float32."""
+    """FFT Poisson solve: +density_k / k^2 with k in cycles per sample, DC zeroed.  float32 for a float32 density
+    (CIC); float64 for a float64 one (NGP), as SciPy's transforms and NumPy's promotion make it in the reference."""
     density = np.asarray(density)
     if density.shape != (grid_size,) * 3:
         raise ValueError(f"density must have shape {(grid_size,) * 3}")
     sim = _engine(grid_size, 1.0, 0)       # the solve does not depend on the box size
+    if density.dtype == np.float64:
+        sim.set_mesh_f64(L.MESH_DENSITY, density)
+        sim.solve_potential_f64()
+        return sim.mesh_f64(L.MESH_POTENTIAL)
     sim.set_mesh(L.MESH_DENSITY, density)
     sim.solve_potential()
     return sim.potential()
 
 
 def gradient(potential: np.ndarray):
-    """np.gradient(potential): tuple of three float32 meshes, one-sided on the faces."""
+    """np.gradient(potential): tuple of three meshes of the potential's dtype, one-sided on the faces."""
     potential = np.asarray(potential)
     g = potential.shape[0]
     sim = _engine(g, 1.0, 0)
+    if potential.dtype == np.float64:
+        sim.set_mesh_f64(L.MESH_POTENTIAL, potential)
+        sim.gradient_f64()
+        return tuple(sim.mesh_f64(w) for w in (L.MESH_GX, L.MESH_GY, L.MESH_GZ))
     sim.set_mesh(L.MESH_POTENTIAL, potential)
     sim.gradient()
     return sim.potential_gradient()
@@ -100,12 +109,18 @@ def NGP(positions: np.ndarray, grid_size: int, box_size: float, masses: np.ndarr
 
 
 def force_NGP(potential_gradient, positions: np.ndarray, grid_size: int, box_size: float) -> np.ndarray:
-    """The gradient meshes at each particle's nearest-grid-point cell -> (N,3) (functions.py:92-97).
-    float32 gradient meshes only (what np.gradient of a float32 potential gives)."""
+    """The gradient meshes at each particle's nearest-grid-point cell -> (N,3) in the meshes' dtype
+    (functions.py:92-97): float64 in the NGP branch proper, float32 for float32 meshes."""
     grads = [np.asarray(a) for a in potential_gradient]
-    if any(a.dtype != np.float32 for a in grads):
-        raise NotImplementedError("force_NGP on the GPU takes float32 gradient meshes")
     sim = _engine(grid_size, box_size, len(positions))
+    if all(a.dtype == np.float64 for a in grads):
+        for which, a in zip((L.MESH_GX, L.MESH_GY, L.MESH_GZ), grads):
+            sim.set_mesh_f64(which, a)
+        sim.set_particles(positions, None, None)
+        sim.compute_forces_ngp_f64()
+        return sim.forces_f64()
+    if any(a.dtype != np.float32 for a in grads):
+        raise TypeError("force_NGP takes three float32 or three float64 gradient meshes")
     for which, a in zip((L.MESH_GX, L.MESH_GY, L.MESH_GZ), grads):
         sim.set_mesh(which, a)
     sim.set_particles(positions, None, None)
@@ -122,7 +137,14 @@ def compute_kinetic_energy(velocities, masses):
 
 
 def compute_potential_energy(positions, masses, potential, grid_size, box_size):
-    """0.5 * sum(m * potential[nearest cell]) (functions.py:356-361), summed in float64 on the GPU."""
+    """0.5 * sum(m * potential[nearest cell]) (functions.py:356-361), summed in float64 on the GPU; the products
+    are float64 too when the potential is (the NGP branch)."""
+    potential = np.asarray(potential)
+    if potential.dtype == np.float64:
+        sim = _engine(grid_size, box_size, len(positions), ngp=True)
+        sim.set_mesh_f64(L.MESH_POTENTIAL, potential)
+        sim.set_particles(positions, None, masses)
+        return sim.energies()[1]
     sim = _engine(grid_size, box_size, len(positions))
     sim.set_mesh(L.MESH_POTENTIAL, potential)
     sim.set_particles(positions, None, masses)

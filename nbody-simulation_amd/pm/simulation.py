@@ -11,14 +11,15 @@ class Simulation:
 
     def __init__(self, grid_size, box_size, positions=None, velocities=None, masses=None,
                  interpolation="CIC", capacity=None, device=0, timing=False, fused_gradient=False, rocfft_only=False):
-        if interpolation != "CIC":
-            raise NotImplementedError("only the CIC branch (main.py:9 default) runs on the GPU path")
+        if interpolation not in ("CIC", "NGP"):
+            raise ValueError(f"interpolation must be 'CIC' or 'NGP' (main.py:9, 40-41), got {interpolation!r}")
+        self.interpolation = interpolation
         self.lib = L.load()
         self.grid_size, self.box_size = int(grid_size), box_size
         n = 0 if positions is None else len(positions)
         self.capacity = int(capacity if capacity is not None else max(n, 1))
         flags = ((L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
-                 | (L.FLAG_ROCFFT_ONLY if rocfft_only else 0))
+                 | (L.FLAG_ROCFFT_ONLY if rocfft_only else 0) | (L.FLAG_NGP if interpolation == "NGP" else 0))
         self.ctx = self.lib.pm_create(self.grid_size, float(box_size), self.capacity, int(device), flags)
         if not self.ctx:
             raise L.PMError("pm_create failed: " + self.lib.pm_last_error(None).decode())
@@ -102,10 +103,34 @@ class Simulation:
     def deposit_ngp(self):
         self._ck(self.lib.pm_deposit_ngp(self.ctx))
 
-    def density_f64(self):
+    def mesh_f64(self, which):
         out = np.empty((self.grid_size,) * 3, np.float64)
-        self._ck(self.lib.pm_get_mesh_f64(self.ctx, L.MESH_DENSITY, L.ptr(out)))
+        self._ck(self.lib.pm_get_mesh_f64(self.ctx, which, L.ptr(out)))
         return out
+
+    def set_mesh_f64(self, which, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != (self.grid_size,) * 3:
+            raise ValueError(f"mesh must have shape {(self.grid_size,) * 3}, got {a.shape}")
+        self._ck(self.lib.pm_set_mesh_f64(self.ctx, which, L.ptr(a)))
+
+    def density_f64(self):
+        return self.mesh_f64(L.MESH_DENSITY)
+
+    # the NGP branch in float64 (functions.py:73-89, main.py:54, functions.py:92-97 on NGP's float64 mesh)
+    def solve_potential_f64(self):
+        self._ck(self.lib.pm_potential_f64(self.ctx))
+
+    def gradient_f64(self):
+        self._ck(self.lib.pm_gradient_f64(self.ctx))
+
+    def compute_forces_ngp_f64(self):
+        self._ck(self.lib.pm_forces_ngp_f64(self.ctx))
+
+    def forces_f64(self):
+        f = np.empty((self.n, 3), np.float64)
+        self._ck(self.lib.pm_get_forces_f64(self.ctx, L.ptr(f)))
+        return f
 
     def compute_forces_ngp(self):
         self._ck(self.lib.pm_forces_ngp(self.ctx))
@@ -113,7 +138,7 @@ class Simulation:
     def synchronize(self):
         self._ck(self.lib.pm_synchronize(self.ctx))
 
-    def set_flags(self, timing=False, fused_gradient=False):
+    def set_flags(self, timing=False, fused_gradient=False):        # the interpolation branch stays as created
         flags = (L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
         self._ck(self.lib.pm_set_flags(self.ctx, flags))
 

@@ -176,6 +176,24 @@ def force_NGP(potential_gradient, positions, grid_size, box_size):
     return np.stack([g[i[:, 0], i[:, 1], i[:, 2]] for g in potential_gradient], axis=1)
 
 
+def pm_step_ngp(positions, velocities, masses, grid_size, box_size, dt, keep=False):
+    """One pass of main.py:50-60 with CIC_interpolation = False (main.py:9, 40-41): NGP's float64 mesh makes the
+    potential, its gradient and the forces float64.  The kick / drift / wrap lines are main.py:58-60 verbatim in
+    NumPy, so their dtype rules are NumPy's own."""
+    density = NGP(positions, grid_size, box_size, masses)
+    potential = compute_potential(density, grid_size)
+    grad = np.gradient(potential)
+    forces = force_NGP(grad, positions, grid_size, box_size)
+    velocities = velocities.copy()
+    positions = positions.copy()
+    velocities += forces * dt
+    positions += velocities * dt
+    positions = positions.astype(np.float32) % box_size
+    if keep:
+        return positions, velocities, dict(density=density, potential=potential, grad=grad, forces=forces)
+    return positions, velocities
+
+
 def compute_kinetic_energy(velocities, masses):
     """functions.py:352-354."""
     return 0.5 * np.sum(masses * np.sum(velocities ** 2, axis=1))

@@ -496,6 +496,65 @@ def test_ngp_variants(pm, golden):
     F.release()
 
 
+@pytest.mark.parametrize("tag", ["", "d_"])
+def test_ngp_branch_resident(pm, golden, tag):
+    """Simulation(interpolation="NGP"): main.py:50-60 with CIC_interpolation = False, every mesh and the forces in
+    float64.  Tolerances: density 1e-12 relative (cells of more than 64 particles are summed in another order than
+    np.add.at), potential / gradient / forces 1e-12 of their largest value (rocFFT vs pocketfft in float64), float32
+    positions 1e-5 L, velocities 1e-5 max|v| after 12 steps."""
+    from pm import _lib as Lb
+    g = golden("ngp_n10000_g32.npz")
+    G, L, dt, K = int(g["G"]), int(g["L"]), float(g["dt"]), int(g["K"])
+    x0, v0 = g["pos0"], g["vel0"]
+    if tag:
+        x0, v0 = x0.astype(np.float64), v0.astype(np.float64)
+    with pm.Simulation(G, L, x0, v0, g["mass"], interpolation="NGP") as sim:
+        sim.deposit_ngp()
+        assert np.allclose(sim.density_f64(), g[tag + "s0_density"], rtol=1e-12, atol=0)
+        sim.solve_potential_f64()
+        phi = sim.mesh_f64(Lb.MESH_POTENTIAL)
+        assert np.abs(phi - g[tag + "s0_potential"]).max() <= 1e-12 * np.abs(g[tag + "s0_potential"]).max()
+        sim.gradient_f64()
+        for w, name in zip((Lb.MESH_GX, Lb.MESH_GY, Lb.MESH_GZ), ("gx", "gy", "gz")):
+            ref = g[tag + "s0_" + name]
+            assert np.abs(sim.mesh_f64(w) - ref).max() <= 1e-12 * np.abs(ref).max()
+        sim.compute_forces_ngp_f64()
+        f = sim.forces_f64()
+        assert f.dtype == np.float64 and np.abs(f - g[tag + "s0_forces"]).max() <= 1e-12 * np.abs(g[tag + "s0_forces"]).max()
+        for step in range(K):
+            sim.step(dt)
+            if step == 0:
+                ke, pe = sim.energies()
+                assert abs(ke - g[tag + "s0_KE"]) <= 1e-6 * abs(g[tag + "s0_KE"])
+                assert abs(pe - g[tag + "s0_PE"]) <= 1e-6 * abs(g[tag + "s0_PE"])
+            if step + 1 in (1, 5, K):
+                x, v = sim.positions(), sim.velocities()
+                xr, vr = g[f"{tag}x{step + 1}"], g[f"{tag}v{step + 1}"]
+                assert x.dtype == np.float32 and v.dtype == vr.dtype
+                dx = np.abs(x.astype(np.float64) - xr)
+                assert np.minimum(dx, L - dx).max() <= 1e-5 * L, (tag, step)
+                assert np.abs(v - vr).max() <= 1e-5 * np.abs(vr).max(), (tag, step)
+    # the trajectory / energy loop runs the same branch
+    with pm.Simulation(G, L, x0, v0, g["mass"], interpolation="NGP") as sim:
+        traj, en = sim.run(5, dt, energy_every=10)
+        dx = np.abs(traj[4].astype(np.float64) - g[tag + "x5"])
+        assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+        assert abs(en[0, 0] - g[tag + "s0_KE"]) <= 1e-6 * abs(g[tag + "s0_KE"])
+    # and the stand-alone functions keep the reference's dtypes
+    from pm import functions as F
+    d = F.NGP(g["pos0"], G, L, g["mass"])
+    phi = F.compute_potential(d, G)
+    grad = F.gradient(phi)
+    f = F.force_NGP(grad, g["pos0"], G, L)
+    assert phi.dtype == np.float64 and grad[0].dtype == np.float64 and f.dtype == np.float64
+    assert np.abs(f - g["s0_forces"]).max() <= 1e-12 * np.abs(g["s0_forces"]).max()
+    pe = F.compute_potential_energy(g["x1"], g["mass"], phi, G, L)
+    assert abs(pe - g["s0_PE"]) <= 1e-9 * abs(g["s0_PE"])
+    F.release()
+    with pytest.raises(ValueError):
+        pm.Simulation(G, L, interpolation="TSC")
+
+
 def test_errors(pm):
     lib = pm.load()
     assert not lib.pm_create(1, 1.0, 10, 0, 0)

@@ -89,6 +89,31 @@ def test_ngp_variants(golden):
     assert np.array_equal(O.force_NGP(grad, g["pos0"], G, L), g["ngp_forces"])
 
 
+@pytest.mark.parametrize("tag", ["", "d_"])
+def test_ngp_branch_k_steps_bit_exact(golden, tag):
+    """main.py:50-60 with CIC_interpolation = False: float64 meshes and forces; float32 particles (tag "") and the
+    shipped run's float64 velocities with float64 positions during step 0 (tag "d_")."""
+    g = golden("ngp_n10000_g32.npz")
+    G, L, dt, K = int(g["G"]), int(g["L"]), float(g["dt"]), int(g["K"])
+    x, v = g["pos0"], g["vel0"]
+    if tag:
+        x, v = x.astype(np.float64), v.astype(np.float64)
+    for step in range(K):
+        if step == 0:
+            x, v, keep = O.pm_step_ngp(x, v, g["mass"], G, L, dt, keep=True)
+            assert keep["potential"].dtype == np.float64 and keep["forces"].dtype == np.float64
+            assert np.array_equal(keep["density"], g[tag + "s0_density"])
+            assert np.array_equal(keep["potential"], g[tag + "s0_potential"])
+            for a, name in zip(keep["grad"], ("gx", "gy", "gz")):
+                assert np.array_equal(a, g[tag + "s0_" + name])
+            assert np.array_equal(keep["forces"], g[tag + "s0_forces"])
+        else:
+            x, v = O.pm_step_ngp(x, v, g["mass"], G, L, dt)
+        if step + 1 in (1, 5, K):
+            assert x.dtype == np.float32 and v.dtype == g[f"{tag}v{step + 1}"].dtype
+            assert np.array_equal(x, g[f"{tag}x{step + 1}"]) and np.array_equal(v, g[f"{tag}v{step + 1}"])
+
+
 def test_import_galaxy(golden):
     g = golden("c1mini_g50.npz")
     p1 = os.path.join(GOLDEN, "galaxy_ellipse_importance_1052_n5000.npz")

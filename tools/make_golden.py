@@ -138,6 +138,40 @@ def make_uniform():
     print("uniform: max|F0|", np.abs(d["s0_forces"]).max(), "max dens", d["s0_density"].max())
 
 
+def make_ngp():
+    """The nearest-grid-point branch (CIC_interpolation = False, main.py:9, 40-41) over K steps: float64 meshes.
+    float32 particles, and the same set with float64 velocities and float64 positions during step 0 (the dtypes of
+    the shipped two-galaxy run)."""
+    N, G, L, dt, K = 10000, 32, 10000, 0.005, 12
+    rng = np.random.default_rng(5)
+    pos = (rng.random((N, 3)) * L).astype(np.float32)
+    pos[: N // 4] = (0.3 * L + rng.normal(0, 0.02 * L, (N // 4, 3))).astype(np.float32)     # a clump
+    vel = rng.normal(0.0, 3.0e4, (N, 3)).astype(np.float32)
+    mass = (rng.random(N) + 0.5).astype(np.float32) * np.float32(3.0e4)
+    d = dict(pos0=pos, vel0=vel, mass=mass, G=G, L=L, dt=dt, K=K)
+    for tag, p0, v0 in (("", pos, vel), ("d_", pos.astype(np.float64), vel.astype(np.float64))):
+        positions, velocities = p0.copy(), v0.copy()
+        for step in range(K):
+            density = F.NGP(positions, G, L, mass)                      # main.py:50
+            potential = F.compute_potential(density, G)                 # main.py:51
+            grad = np.gradient(potential)                               # main.py:54
+            forces = F.force_NGP(grad, positions, G, L)                 # main.py:55
+            if step == 0:
+                d[tag + "s0_density"], d[tag + "s0_potential"], d[tag + "s0_forces"] = density, potential, forces
+                d[tag + "s0_gx"], d[tag + "s0_gy"], d[tag + "s0_gz"] = grad
+            velocities += forces * dt                                   # main.py:58
+            positions += velocities * dt                                # main.py:59
+            positions = positions.astype(np.float32) % L                # main.py:60
+            if step % 10 == 0:                                          # main.py:64-67
+                d[f"{tag}s{step}_KE"] = np.float64(F.compute_kinetic_energy(velocities, mass))
+                d[f"{tag}s{step}_PE"] = np.float64(F.compute_potential_energy(positions, mass, potential, G, L))
+            if step + 1 in (1, 5, K):
+                d[f"{tag}x{step + 1}"], d[f"{tag}v{step + 1}"] = positions.copy(), velocities.copy()
+        assert d[tag + "s0_potential"].dtype == np.float64 and d[tag + "s0_forces"].dtype == np.float64
+    np.savez_compressed(os.path.join(OUT, "ngp_n10000_g32.npz"), **d)
+    print("ngp: max|F0|", np.abs(d["s0_forces"]).max(), "dtypes", d["x1"].dtype, d["v1"].dtype, d["d_v1"].dtype)
+
+
 def make_c1mini():
     """The shipped two-galaxy run (main.py:25-33) at 5000 + 5000 particles.
 
@@ -227,3 +261,5 @@ if __name__ == "__main__":
         make_uniform()
     if "c1mini" in which:
         make_c1mini()
+    if "ngp" in which:
+        make_ngp()
