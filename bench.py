@@ -186,8 +186,8 @@ def main():
 
     n, G, L = args.n, args.grid, BOX
     m = G ** 3
-    # every rank holds an independent replica of the workload (its own seed): until the mesh is
-    # slab-decomposed across ranks, multi-GPU runs are N replicas
+    # every rank holds an independent replica of the workload (its own seed); --parallelism slab runs ONE
+    # simulation over the ranks instead, and slab_probe() below reports that run beside this one
     pos, vel, mass = make_workload(args.workload, n, L, 1052 + rank)
     fused = not args.no_fused_gradient
     sim = pm.Simulation(G, L, pos, vel, mass, device=local_rank, fused_gradient=fused)
