@@ -81,6 +81,25 @@ __device__ __forceinline__ uint32_t cell_key(const cell_t &c, const pm_geom &g)
 
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
 
+// The hardware hands workgroup b to XCD b % 8, and every XCD has an L2 of its own.  xcd_block<C>() renumbers the
+// workgroups so that each XCD takes C consecutive blocks of every run of 8 C blocks (C = 0: no renumbering).  The
+// gather uses C = 16: the eight XCDs still work side by side on one neighbourhood of the mesh (what they read of the
+// potential was written last by the previous kernel and sits in the last-level cache), but the mesh rows under 4096
+// consecutive particles are fetched into one L2 only.  -3 % for that kernel on the clustered set, -1.5 % on the uniform
+// one; one contiguous eighth of the particles per XCD is 30 % slower.
+template <int C>
+__device__ __forceinline__ uint32_t xcd_block()
+{
+    if (C == 0) return blockIdx.x;
+    const uint32_t b = blockIdx.x, span = 8u * (uint32_t)(C ? C : 1), base = b / span * span;
+    if (base + span > gridDim.x) return b;           // the last, partial run keeps its order
+    const uint32_t o = b - base;
+    return base + (o & 7u) * (uint32_t)C + (o >> 3);
+}
+#ifndef PM_GATHER_XCD
+#define PM_GATHER_XCD 16
+#endif
+
 // ---- host copies ---------------------------------------------------------------------------
 
 template <typename TP>
@@ -725,7 +744,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
          const float *__restrict__ phi, float *__restrict__ forces, uint32_t *__restrict__ key_next, int64_t n, pm_geom g,
          double dt, bool integrate, outbox_t ob = outbox_t{})
 {
-    int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    int64_t r = (int64_t)xcd_block<PM_GATHER_XCD>() * BLOCK + threadIdx.x;
     if (r >= n) return;
     const int G = g.G;
     const pm_prec<TP> p = Pin[r];
