@@ -623,6 +623,7 @@ int pm_energies(pm_ctx *c, double *ke, double *pe)
     TRY(whole_mesh(c));
     TRY(need_particles(c));
     if (!ke || !pe) return fail(c, PM_EINVAL, "NULL buffer");
+    if ((c->flags & PM_FLAG_NGP) && !c->potential64) return fail(c, PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
     HIP_TRY(c, hipSetDevice(c->device));
     double *res = c->diag + 2 * 1024;
     HIP_TRY(c, pm_launch_energies(c, res, res + 1));

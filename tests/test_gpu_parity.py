@@ -553,6 +553,13 @@ def test_ngp_branch_resident(pm, golden, tag):
     F.release()
     with pytest.raises(ValueError):
         pm.Simulation(G, L, interpolation="TSC")
+    with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"], interpolation="NGP") as sim:
+        with pytest.raises(pm.PMError):
+            sim.energies()                  # no potential before the first solve
+        with pytest.raises(pm.PMError):
+            sim.gradient_f64()
+        with pytest.raises(pm.PMError):
+            sim.forces_f64()
 
 
 def test_errors(pm):
