@@ -212,6 +212,7 @@ pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int
     c->slab = slab;
     c->nslabs = grid_size / nplanes;
     c->g.i0 = plane0; c->g.Gs = nplanes; c->g.Gd = slab ? nplanes + 1 : grid_size; c->g.lo = slab ? 1 : 0;
+    c->g.sb = (c->fft_custom && !slab) ? pm_fft_spectrum_interleave(grid_size) : 0;
     c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
     if (create_impl(c) != PM_OK) {
         g_create_error = c->err;

@@ -35,8 +35,12 @@ __device__ __forceinline__ float freq(int a, int G, double invG)
 
 struct col_pass {
     float2 *spec;
-    int64_t outer_stride;   // elements between consecutive `outer` indices
-    int64_t row_stride;     // elements between consecutive rows of the transform axis
+    // element (outer, row, col) of `spec` is at
+    //   (outer >> o_shift) * o_hi + (outer & (2^o_shift - 1)) * o_lo + (row >> r_shift) * r_hi + (row & (2^r_shift - 1)) * r_lo + col:
+    // plain strides with both shifts 0, the interleaved planes of pm_spec_row otherwise
+    int64_t o_hi, o_lo, r_hi, r_lo;
+    int o_shift, r_shift;
+    int64_t row_stride;     // elements between consecutive rows of `blocks` (BLK != 0)
     int tiles;              // column tiles per outer index
     int ncols;              // valid columns per outer index (G/2 + 1)
     int G;
@@ -106,7 +110,10 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
     const int outer = lb / per_outer, sub = lb % per_outer;
     const int col = p.tile0 * COLS + sub * C + c;
     const bool valid = col < p.ncols;
-    float2 *g = p.spec + (int64_t)outer * p.outer_stride + col;
+    float2 *g = p.spec + (int64_t)(outer >> p.o_shift) * p.o_hi + (int64_t)(outer & ((1 << p.o_shift) - 1)) * p.o_lo + col;
+    auto in_spec = [&](int row) -> float2 & {
+        return g[(int64_t)(row >> p.r_shift) * p.r_hi + (int64_t)(row & ((1 << p.r_shift) - 1)) * p.r_lo];
+    };
     // the same column in the all-to-all buffer: plane `outer`'s rows of block b start at (b * Gs + outer) * Gs * pitch
     float2 *gb = BLK ? p.blocks + ((int64_t)outer << p.gs_shift) * p.row_stride + col : nullptr;
     auto in_blocks = [&](int row) -> float2 & {
@@ -124,7 +131,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
         for (int r = 0; r < R1; ++r) {
             int row = jl + TPC * b + 64 * r;
             if (BLK == 2) v[b * R1 + r] = valid ? in_blocks(row) : make_float2(0.0f, 0.0f);
-            else v[b * R1 + r] = valid ? g[(int64_t)row * p.row_stride] : make_float2(0.0f, 0.0f);
+            else v[b * R1 + r] = valid ? in_spec(row) : make_float2(0.0f, 0.0f);
         }
 
     auto stage1_out = [&](auto dir) {
@@ -219,7 +226,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
             for (int r = 0; r < 8; ++r) {
                 int row = jl + TPC * b + Q * r;
                 if (BLK == 1) in_blocks(row) = v[b * 8 + r];
-                else g[(int64_t)row * p.row_stride] = v[b * 8 + r];
+                else in_spec(row) = v[b * 8 + r];
             }
     }
 }
@@ -242,7 +249,7 @@ constexpr int ROWS_PER_WAVE = PM_ROWS_PER_WAVE;
 
 template <int N>
 __global__ void __launch_bounds__(FFT_BLOCK)
-k_row_r2c(const float *__restrict__ in, float2 *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
+k_row_r2c(const float *__restrict__ in, float2 *__restrict__ out, int pitch, const float2 *__restrict__ twiddle, int sb)
 {
     constexpr int E = N / 128, M = N / 2;
     __shared__ float2 tw[N];
@@ -258,13 +265,14 @@ k_row_r2c(const float *__restrict__ in, float2 *__restrict__ out, int pitch, con
 #pragma unroll
         for (int r = 0; r < E; ++r) v[r] = src[j + 64 * r];
         wave_fft<E, -1>(v, buf, tw, j);
-        wave_r2c_split<E>(v, buf, tw, j, out + (row0 + rr) * pitch);
+        const int64_t row = row0 + rr;          // mesh row i * N + j
+        wave_r2c_split<E>(v, buf, tw, j, out + pm_spec_row(N, sb, (int)(row / N), (int)(row % N)) * pitch);
     }
 }
 
 template <int N>
 __global__ void __launch_bounds__(FFT_BLOCK)
-k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, const float2 *__restrict__ twiddle)
+k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, const float2 *__restrict__ twiddle, int sb)
 {
     constexpr int E = N / 128, M = N / 2;
     __shared__ float2 tw[N];
@@ -276,7 +284,8 @@ k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, con
     // last planes first: the pass along y before this one ends with them, and the gather after it starts with the first
     const int64_t row0 = ((int64_t)(gridDim.x - 1 - blockIdx.x) * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-        const float2 *src = in + (row0 + rr) * pitch;
+        const int64_t row = row0 + rr;
+        const float2 *src = in + pm_spec_row(N, sb, (int)(row / N), (int)(row % N)) * pitch;
         float2 x[E], v[E];
 #pragma unroll
         for (int r = 0; r < E; ++r) x[r] = src[j + 64 * r];
@@ -314,15 +323,16 @@ hipError_t launch_col_any(pm_ctx *c, int dir, const col_pass &p, int blocks)
     return dir < 0 ? launch_col<1024, -1, false>(c, p, blocks) : launch_col<1024, 1, false>(c, p, blocks);
 }
 
-hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int64_t rows)
+// sb: the interleaving of `spec` (0 for the plane buffers of a slab)
+hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int64_t rows, int sb)
 {
     const int blocks = (int)(rows / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
     if (c->g.G == 512) {
-        if (forward) k_row_r2c<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle);
-        else k_row_c2r<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle);
+        if (forward) k_row_r2c<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle, sb);
+        else k_row_c2r<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle, sb);
     } else {
-        if (forward) k_row_r2c<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle);
-        else k_row_c2r<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle);
+        if (forward) k_row_r2c<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle, sb);
+        else k_row_c2r<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle, sb);
     }
     return hipGetLastError();
 }
@@ -330,6 +340,18 @@ hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *rea
 }  // namespace
 
 bool pm_fft_custom_supported(int G) { return G == 512 || G == 1024; }
+
+// log2 of the planes whose rows the whole-mesh half spectrum interleaves (pm_spec_row).  At N = 1024 a third of the
+// address translations of the pass along i miss the CU's TLB in plain order (1024 rows, 4.3 MB apart, per tile); four
+// interleaved planes cut its time by 20 % and cost the passes along j, whose rows move four times further apart,
+// 4 %: -0.45 ms per step.  More planes help the one and hurt the other more; at N = 512 the plain order is fastest.
+#ifndef PM_SPEC_B_512
+#define PM_SPEC_B_512 0
+#endif
+#ifndef PM_SPEC_B_1024
+#define PM_SPEC_B_1024 2
+#endif
+int pm_fft_spectrum_interleave(int G) { return G == 512 ? PM_SPEC_B_512 : G == 1024 ? PM_SPEC_B_1024 : 0; }
 
 int pm_fft_pitch(int G)
 {
@@ -354,7 +376,7 @@ hipError_t pm_fft_upload_twiddles(pm_ctx *c)
 // z axis: density (G,G,G) -> half spectrum (forward), half spectrum -> potential (inverse)
 hipError_t pm_launch_row_fft(pm_ctx *c, bool forward)
 {
-    return launch_rows(c, forward, c->density, c->potential, c->spectrum, (int64_t)c->g.G * c->g.G);
+    return launch_rows(c, forward, c->density, c->potential, c->spectrum, (int64_t)c->g.G * c->g.G, c->g.sb);
 }
 
 static col_pass pass_for(pm_ctx *c, float2 *spec)
@@ -366,23 +388,36 @@ static col_pass pass_for(pm_ctx *c, float2 *spec)
     return p;
 }
 
+static void plain_strides(col_pass &p, int64_t outer_stride, int64_t row_stride)
+{
+    p.o_shift = p.r_shift = 0;
+    p.o_hi = outer_stride; p.r_hi = row_stride; p.o_lo = p.r_lo = 0;
+}
+
+// the context's own half spectrum (rows interleaved as pm_spec_row says): along j (outer = plane i) or along i (outer = j)
+static void spectrum_strides(pm_ctx *c, col_pass &p, bool along_i)
+{
+    const int64_t G = c->g.G, P = c->g.Ghp;
+    const int sb = c->g.sb;
+    if (along_i) { p.o_shift = 0; p.o_hi = P << sb; p.o_lo = 0; p.r_shift = sb; p.r_hi = (G << sb) * P; p.r_lo = P; }
+    else { p.o_shift = sb; p.o_hi = (G << sb) * P; p.o_lo = P; p.r_shift = 0; p.r_hi = P << sb; p.r_lo = 0; }
+}
+
 // dir < 0: forward along j.  dir > 0: inverse along j.  dir == 0: forward along i, Green multiply, inverse along i.
 hipError_t pm_launch_col_fft(pm_ctx *c, int dir)
 {
-    const int G = c->g.G, P = c->g.Ghp;
+    const int G = c->g.G;
     col_pass p = pass_for(c, c->spectrum);
-    if (dir == 0) { p.outer_stride = P; p.row_stride = (int64_t)G * P; }
-    else { p.outer_stride = (int64_t)G * P; p.row_stride = P; }
+    spectrum_strides(c, p, dir == 0);
     return launch_col_any(c, dir, p, G * p.tiles);
 }
 
 // The same on column tiles [tile0, tile0 + ntiles) only (a tile is 16 neighbouring columns c of all rows).
 hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles)
 {
-    const int G = c->g.G, P = c->g.Ghp;
+    const int G = c->g.G;
     col_pass p = pass_for(c, c->spectrum);
-    if (dir == 0) { p.outer_stride = P; p.row_stride = (int64_t)G * P; }
-    else { p.outer_stride = (int64_t)G * P; p.row_stride = P; }
+    spectrum_strides(c, p, dir == 0);
     p.tile0 = tile0; p.ntiles = ntiles;
     return launch_col_any(c, dir, p, G * ntiles);
 }
@@ -393,14 +428,14 @@ int pm_fft_tiles(const pm_ctx *c) { return c->g.Ghp / COLS; }
 
 hipError_t pm_launch_row_fft_planes(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int planes)
 {
-    return launch_rows(c, forward, real_in, real_out, spec, (int64_t)planes * c->g.G);
+    return launch_rows(c, forward, real_in, real_out, spec, (int64_t)planes * c->g.G, 0);
 }
 
 hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes)
 {
     const int G = c->g.G, P = c->g.Ghp;
     col_pass p = pass_for(c, spec);
-    p.outer_stride = (int64_t)G * P; p.row_stride = P;
+    plain_strides(p, (int64_t)G * P, P);
     return launch_col_any(c, dir < 0 ? -1 : 1, p, planes * p.tiles);
 }
 
@@ -410,7 +445,8 @@ hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *bl
 {
     const int G = c->g.G, P = c->g.Ghp;
     col_pass p = pass_for(c, spec);
-    p.outer_stride = (int64_t)G * P; p.row_stride = P;
+    plain_strides(p, (int64_t)G * P, P);
+    p.row_stride = P;
     p.blocks = blocks;
     p.gs_shift = 0;
     while ((1 << p.gs_shift) < planes) ++p.gs_shift;
@@ -425,6 +461,7 @@ hipError_t pm_launch_solve_x(pm_ctx *c, float2 *spec_t, int y0, int ny)
 {
     const int P = c->g.Ghp;
     col_pass p = pass_for(c, spec_t);
-    p.outer_stride = P; p.row_stride = (int64_t)ny * P; p.outer0 = y0;
+    plain_strides(p, P, (int64_t)ny * P);
+    p.outer0 = y0;
     return launch_col_any(c, 0, p, ny * p.tiles);
 }

@@ -24,7 +24,18 @@ struct pm_geom {
     int Gs;         // owned planes; a particle is owned by the slab that holds its cell's plane i
     int Gd;         // planes the deposit writes: G (periodic along i), or Gs + 1 (the last one belongs to the next slab)
     int lo;         // planes of the potential buffer below plane i0 (0, or 1 in a slab)
+    int sb;         // half spectrum: rows of 2^sb neighbouring planes are interleaved (pm_spec_row); 0 = plain (i, j) order
 };
+
+// Row (i, j) of the half spectrum is row pm_spec_row(...) of the buffer (times the pitch).  With sb = 0 that is
+// i * G + j.  Whole-mesh contexts on the hand-written transforms use sb > 0: the rows j of planes i0 .. i0 + 2^sb - 1
+// alternate, so that a transform along i steps through memory in strides of one row for 2^sb rows at a time instead
+// of G rows every time (a 16-column tile of the pass along i then touches G / 2^sb regions of memory, not G: its
+// address translations fit the TLBs), while the pass along j still spans only 2^sb planes' worth of memory.
+__host__ __device__ inline int64_t pm_spec_row(int G, int sb, int i, int j)
+{
+    return ((((int64_t)(i >> sb) * G + j) << sb) | (int64_t)(i & ((1 << sb) - 1)));
+}
 
 // What leaves a slab: a particle's position and velocity records.
 struct pm_migrant { float x, y, z, m, vx, vy, vz; uint32_t id; };
@@ -152,6 +163,7 @@ hipError_t pm_launch_row_start(pm_ctx *c);
 hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum);
 hipError_t pm_launch_green(pm_ctx *c);
 bool pm_fft_custom_supported(int G);
+int pm_fft_spectrum_interleave(int G);       // log2 of the planes interleaved in a whole-mesh half spectrum (pm_geom::sb)
 int pm_fft_pitch(int G);
 hipError_t pm_fft_upload_twiddles(pm_ctx *c);
 hipError_t pm_launch_col_fft(pm_ctx *c, int dir);

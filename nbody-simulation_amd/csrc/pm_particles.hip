@@ -524,7 +524,7 @@ __device__ __forceinline__ void deposit_chunks4(const pm_frac *__restrict__ F, c
 // or read; the bits are those of writing it and transforming it afterwards.
 template <int NFFT>
 __device__ __forceinline__ void emit_row(double *acc, const float2 *tw, float *__restrict__ density, float2 *__restrict__ spectrum,
-                                         uint32_t row, int G, int pitch)
+                                         uint32_t row, int G, int pitch, int sb)
 {
     const int j = lane_id();
     if constexpr (NFFT != 0) {
@@ -537,7 +537,7 @@ __device__ __forceinline__ void emit_row(double *acc, const float2 *tw, float *_
         }
         float2 *buf = (float2 *)acc;                    // the row's LDS is free once every lane holds its part
         pmfft::wave_fft<E, -1>(v, buf, tw, j);
-        pmfft::wave_r2c_split<E>(v, buf, tw, j, spectrum + (size_t)row * pitch);
+        pmfft::wave_r2c_split<E>(v, buf, tw, j, spectrum + pm_spec_row(NFFT, sb, (int)(row / NFFT), (int)(row % NFFT)) * pitch);
     } else {
         float *out = density + (size_t)row * G;
         for (int c = j; c < G; c += 64) out[c] = (float)acc[c];
@@ -545,11 +545,11 @@ __device__ __forceinline__ void emit_row(double *acc, const float2 *tw, float *_
 }
 
 template <int NFFT>
-__device__ __forceinline__ void emit_empty_row(float *__restrict__ density, float2 *__restrict__ spectrum, uint32_t row, int G, int pitch)
+__device__ __forceinline__ void emit_empty_row(float *__restrict__ density, float2 *__restrict__ spectrum, uint32_t row, int G, int pitch, int sb)
 {
     const int j = lane_id();
     if constexpr (NFFT != 0) {
-        float2 *dst = spectrum + (size_t)row * pitch;
+        float2 *dst = spectrum + pm_spec_row(NFFT, sb, (int)(row / NFFT), (int)(row % NFFT)) * pitch;
         for (int c = j; c <= G / 2; c += 64) dst[c] = make_float2(0.0f, 0.0f);
     } else {
         float *out = density + (size_t)row * G;
@@ -615,7 +615,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         t.longest = len > t.longest ? len : t.longest;
     }
     if (t.longest == 0 && !crowded) {
-        emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp);
+        emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp, g.sb);
         return;
     }
     uint32_t entry = 0;
@@ -642,7 +642,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         double *out = light_rows + (size_t)entry * G;
         for (int c = lane_id(); c < G; c += 64) out[c] = acc[c];
     } else {
-        emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp);
+        emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp, g.sb);
     }
 }
 
@@ -707,7 +707,7 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_un
             lds_rows[c] = sum;
         }
         __syncthreads();
-        if (threadIdx.x < 64) emit_row<NFFT>(lds_rows, tw, density, spectrum, entry.x, G, g.Ghp);
+        if (threadIdx.x < 64) emit_row<NFFT>(lds_rows, tw, density, spectrum, entry.x, G, g.Ghp, g.sb);
         __syncthreads();
     }
 }
