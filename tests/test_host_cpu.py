@@ -40,6 +40,27 @@ def test_particle_array_validation():
     assert b.flags.c_contiguous and b.dtype == np.float32
 
 
+def test_simulation_arguments_are_checked_before_the_gpu_is_touched():
+    import pm
+    with pytest.raises(ValueError):
+        pm.Simulation(8, 100.0, interpolation="TSC")            # main.py:9 knows CIC and NGP only
+
+
+def test_spectrum_row_interleave_is_a_permutation():
+    """Row (i, j) -> row of the half-spectrum buffer (pm_spec_row in csrc/pm_internal.hpp), restated: every buffer
+    row is used exactly once, and with no interleave it is i * G + j."""
+    def spec_row(G, sb, i, j):
+        return (((i >> sb) * G + j) << sb) | (i & ((1 << sb) - 1))
+    G = 32
+    i, j = np.meshgrid(np.arange(G), np.arange(G), indexing="ij")
+    assert np.array_equal(spec_row(G, 0, i, j), i * G + j)
+    for sb in (1, 2, 4):
+        rows = spec_row(G, sb, i, j).ravel()
+        assert np.array_equal(np.sort(rows), np.arange(G * G))
+        # along i, 2^sb consecutive planes are consecutive rows; along j the stride is 2^sb rows
+        assert spec_row(G, sb, 5, 7) - spec_row(G, sb, 4, 7) == 1 and spec_row(G, sb, 4, 8) - spec_row(G, sb, 4, 7) == 1 << sb
+
+
 def test_bench_workloads():
     import bench
     for name in ("uniform", "two_galaxy", "disk"):
