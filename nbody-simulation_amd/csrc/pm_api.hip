@@ -141,6 +141,8 @@ static int create_impl(pm_ctx *c)
     TRY(dalloc(c, &c->key_in, cap + 4));
     TRY(dalloc(c, &c->key_out, cap + 4));
     TRY(dalloc(c, &c->src, cap));
+    TRY(dalloc(c, &c->iota, cap));
+    HIP_TRY(c, pm_sort_fill_iota(c));
     c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, planes * G + 1));
@@ -235,7 +237,7 @@ void pm_destroy(pm_ctx *c)
     hipStreamSynchronize(c->stream);
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac);
-    hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
+    hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->iota); hipFree(c->sort_tmp);
     hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);

@@ -90,6 +90,7 @@ struct pm_ctx {
 
     // binning scratch
     uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;
+    uint32_t *iota = nullptr;           // 0, 1, 2, ...: the values the sort starts from (written once)
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
@@ -156,6 +157,7 @@ pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int
 hipError_t pm_launch_pack(pm_ctx *c, const void *pos_aos, const float *mass, const void *vel_aos);
 hipError_t pm_launch_cell_keys(pm_ctx *c);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);
+hipError_t pm_sort_fill_iota(pm_ctx *c);      // c->iota[r] = r, once per context
 size_t pm_sort_tmp_bytes(int64_t cap);
 hipError_t pm_launch_reorder(pm_ctx *c);
 hipError_t pm_settle_velocities(pm_ctx *c);     // must run before src is overwritten by a new sort
