@@ -133,6 +133,7 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(c, hipHostMalloc((void **)&c->units_seen, sizeof(uint32_t), hipHostMallocDefault));
     *c->units_seen = 1;
+    HIP_TRY(c, hipHostGetDevicePointer((void **)&c->units_seen_dev, (void *)c->units_seen, 0));
     for (int s = 0; s < PM_NSTAGES; ++s)
         for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
 
@@ -147,7 +148,8 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, planes * G + 1));
     TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G, cap)));
-    TRY(dalloc(c, &c->counters, 64));
+    TRY(dalloc(c, &c->counters, 128));
+    HIP_TRY(c, hipMemsetAsync(c->counters, 0, 128 * sizeof(uint32_t), c->stream));
     TRY(dalloc(c, &c->row_unit, planes * G + 1));
     TRY(dalloc(c, &c->unit_src, pm_max_units(cap)));
     TRY(dalloc(c, &c->unit_rows, pm_max_units(cap) * 4 * (size_t)G));
@@ -356,7 +358,10 @@ static int potential_impl(pm_ctx *c, bool have_z)
         const int tiles = pm_fft_tiles(c);
         // (measured: 6 tiles of 16 columns at G = 512 gain 1.5 % of the step; at G = 1024, where a tile is 134 MB and
         // a launch fills the GPU only once, any grouping loses to its launch tails)
-        const int group = c->g.G <= 512 ? 6 : tiles;
+#ifndef PM_COL_GROUP
+#define PM_COL_GROUP 6
+#endif
+        const int group = c->g.G <= 512 ? PM_COL_GROUP : tiles;
         for (int t0 = 0; t0 < tiles; t0 += group) {
             const int nt = t0 + group <= tiles ? group : tiles - t0;
             HIP_TRY(c, pm_launch_col_fft_tiles(c, -1, t0, nt));

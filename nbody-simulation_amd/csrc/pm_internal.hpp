@@ -97,7 +97,9 @@ struct pm_ctx {
     uint32_t *row_unit = nullptr;       // per mesh row: first unit of a crowded row, or none
     uint32_t *unit_src = nullptr;       // per unit: the mesh row it is a part of
     uint2 *heavy_rows = nullptr;        // density rows with a crowded source: (row, has a partial sum in light_rows)
-    uint32_t *counters = nullptr;       // units handed out, density rows listed (64 words)
+    uint32_t *counters = nullptr;       // units handed out, density rows listed: two sets of 64 words that take turns
+    int counter_set = 0;                // the set the next deposit uses (zeroed by the deposit before it)
+    volatile uint32_t *units_seen_dev = nullptr;    // units_seen as the device addresses it
     double *unit_rows = nullptr;        // four rows of G doubles per unit
     double *light_rows = nullptr;       // one row of G doubles per listed density row
 

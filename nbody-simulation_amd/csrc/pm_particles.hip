@@ -677,13 +677,20 @@ template <int NFFT>
 __global__ void __launch_bounds__(BLOCK)
 k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, const uint2 *__restrict__ heavy_rows,
             const uint32_t *__restrict__ counters, const double *__restrict__ unit_rows, const double *__restrict__ light_rows,
-            float *__restrict__ density, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle, pm_geom g)
+            float *__restrict__ density, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle, pm_geom g,
+            uint32_t *__restrict__ next_counters, volatile uint32_t *__restrict__ units_seen)
 {
     extern __shared__ double lds_rows[];                // one row of G doubles, then the NFFT twiddles
     const int G = g.G;
     float2 *tw = (float2 *)(lds_rows + G);
     if constexpr (NFFT != 0) {
         for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
+    }
+    // housekeeping of the last kernel of a deposit: the next deposit's counters (the other set: nobody uses it now)
+    // start at zero, and the host learns how many units this one had (a word of page-locked host memory)
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        next_counters[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) *units_seen = counters[COUNTER_UNITS];
     }
     const uint32_t entries = counters[COUNTER_ROWS];
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
@@ -1004,9 +1011,11 @@ static hipError_t deposit_dispatch(pm_ctx *c)
 {
     const int G = c->g.G;
     const uint32_t R = (uint32_t)c->g.Gd * (uint32_t)G, Rs = (uint32_t)c->g.Gs * (uint32_t)G;
-    hipError_t e = hipMemsetAsync(c->counters, 0, 64 * sizeof(uint32_t), c->stream);
-    if (e != hipSuccess) return e;
-    k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, c->counters);
+    // two sets of counters take turns: each deposit's last kernel zeroes the set of the next one
+    uint32_t *counters = c->counters + 64 * c->counter_set, *next_counters = c->counters + 64 * (1 - c->counter_set);
+    c->counter_set = 1 - c->counter_set;
+    hipError_t e = hipSuccess;
+    k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, counters);
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
     const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);
@@ -1020,20 +1029,20 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     // unless recent deposits had no units at all (the count comes back to the host without anyone waiting for
     // it, so it is a step or two old: good enough to decide where to launch a kernel that finds out for itself).
     const bool beside = *c->units_seen != 0;
-    if ((e = hipMemcpyAsync((void *)c->units_seen, c->counters + COUNTER_UNITS, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
     hipStream_t us = beside ? c->side : c->stream;
     if (beside) {
         if ((e = hipEventRecord(c->ev_fork, c->stream)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
     }
-    k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, c->counters,
+    k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, counters,
                                                                   c->unit_rows, c->g);
     if (beside && (e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
     k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
-        c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, c->counters, c->light_rows, c->g);
+        c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g);
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
-    k_sum_units<NFFT><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, c->counters, c->unit_rows,
-                                                                                        c->light_rows, c->density, c->spectrum, c->twiddle, c->g);
+    k_sum_units<NFFT><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
+                                                                                        c->light_rows, c->density, c->spectrum, c->twiddle, c->g,
+                                                                                        next_counters, c->units_seen_dev);
     return hipGetLastError();
 }
 
