@@ -273,6 +273,18 @@ def test_headline_size_properties(pm):
         with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
             sim.step(dt, 2)
             assert np.array_equal(sim.positions(), x_staged) and np.array_equal(sim.velocities(), v_staged)
+    # and the oracle itself at this size (about 5 s of CPU per step): the whole cell order bit for bit, the density
+    # within the deposit's bounds, two full steps within the K-step tolerances
+    ko = O.cell_keys(pos, G, L)
+    order = O.sort_order(ko)
+    assert np.array_equal(keys, ko[order]) and np.array_equal(perm, order)
+    assert_density(d, O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
+    xo, vo = pos, vel
+    for _ in range(2):
+        xo, vo = O.pm_step(xo, vo, mass, G, L, dt)
+    dx = np.abs(x_staged.astype(np.float64) - xo)
+    assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+    assert np.abs(v_staged - vo).max() <= 1e-5 * np.abs(vo).max()
 
 
 def test_single_fourier_mode(pm):
