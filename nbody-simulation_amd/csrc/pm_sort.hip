@@ -5,6 +5,14 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+// block size and keys per thread of the histogram kernel that precedes the passes (16 keys per thread: 14 us less
+// than with 8 at 16.7 M keys; more is slower again)
+#ifndef PM_HIST_BLOCK
+#define PM_HIST_BLOCK 1024
+#endif
+#ifndef PM_HIST_ITEMS
+#define PM_HIST_ITEMS 16
+#endif
 #ifndef PM_SORT_BLOCK
 #define PM_SORT_BLOCK 1024
 #endif
@@ -20,7 +28,7 @@ namespace {
 template <unsigned RADIX>
 using sort_config = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<PM_SORT_BLOCK, PM_SORT_ITEMS>, RADIX,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<PM_HIST_BLOCK, PM_HIST_ITEMS>, rocprim::kernel_config<PM_SORT_BLOCK, PM_SORT_ITEMS>, RADIX,
                                         rocprim::block_radix_rank_algorithm::match>>;
 
 // The values that go in are the storage indices 0, 1, 2, ...: read from a table that is written once, not made by a
