@@ -13,9 +13,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "nbody-simulation_amd")]
 import bench
 import pm
 
-chunks, per = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 500
-n, G, L, dt = 16_777_216, 512, 10000, 0.005
-pos, vel, mass = bench.make_workload("two_galaxy", n, L, 1052)
+# soak.py [chunks [steps_per_chunk [workload [n [G]]]]]
+arg = sys.argv[1:] + [None] * 5
+chunks, per = int(arg[0] or 8), int(arg[1] or 500)
+workload, n, G, L, dt = arg[2] or "two_galaxy", int(arg[3] or 16_777_216), int(arg[4] or 512), 10000, 0.005
+pos, vel, mass = bench.make_workload(workload, n, L, 1052)
 total = float(mass.astype(np.float64).sum())
 with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
     sim.step(dt, 3)
