@@ -574,6 +574,27 @@ def test_ngp_branch_resident(pm, golden, tag):
             sim.forces_f64()
 
 
+def test_main_shaped_driver_runs_both_ways():
+    """examples/run_collision.py = main.py with the reference's constants and inputs: the loop body call by call through
+    pm.functions (reference names, host arrays) and the resident loop give the same energies."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ([], ["--granular"], ["--ngp"], ["--ngp", "--granular"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_collision.py"), "--steps", "12"] + mode,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"12 frames of 10000 particles, total energy (\S+) -> (\S+)", r.stdout)
+        assert m, r.stdout
+        out[tuple(mode)] = (float(m.group(1)), float(m.group(2)))
+    for a, b in (((), ("--granular",)), (("--ngp",), ("--ngp", "--granular"))):
+        for u, v in zip(out[a], out[b]):
+            assert abs(u - v) <= 1e-5 * abs(v), (a, out)
+
+
 def test_errors(pm):
     lib = pm.load()
     assert not lib.pm_create(1, 1.0, 10, 0, 0)
