@@ -574,6 +574,56 @@ def test_ngp_branch_resident(pm, golden, tag):
             sim.forces_f64()
 
 
+def test_random_small_configurations(pm):
+    """Forty random small set-ups against the oracle, two steps each: any grid size from 2 up (odd ones too), any box
+    size, from no particle to a few thousand, positions far outside the box and exactly on cell and box edges, all in
+    one cell, float32 and float64 particles in every combination, fused and staged."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        G = int(rng.choice([2, 3, 4, 5, 7, 8, 9, 16, 17, 24, 31, 32, 33, 40]))
+        L = int(rng.choice([1, 7, 100, 10000, 123457]))
+        n = int(rng.choice([0, 1, 2, 63, 64, 65, 257, 1000, 4099]))
+        kind = case % 4
+        if kind == 0:
+            pos = rng.random((n, 3)) * L
+        elif kind == 1:
+            pos = (rng.random((n, 3)) - 0.5) * 20 * L                      # up to ten boxes away, both signs
+        elif kind == 2:
+            pos = rng.integers(0, G + 1, (n, 3)) * (L / G)                  # on cell edges, and on the box edge itself
+        else:
+            pos = np.full((n, 3), 0.37 * L) + rng.random((n, 3)) * (0.5 * L / G)   # (nearly) one cell
+        vel = rng.normal(0, 0.3 * L, (n, 3))
+        mass = (rng.random(n) + 0.5).astype(np.float32)
+        pdt, vdt = [(np.float32, np.float32), (np.float64, np.float64), (np.float32, np.float64), (np.float64, np.float32)][(case // 4) % 4]
+        pos, vel = pos.astype(pdt), vel.astype(vdt)
+        dt = 0.01
+        fused = bool(case % 2)
+        tag = (case, G, L, n, kind, pdt.__name__, vdt.__name__, fused)
+        with pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused) as sim:
+            if n:
+                keys, perm = sim.cell_keys()
+                ko = O.cell_keys(pos, G, L)
+                order = O.sort_order(ko)
+                assert np.array_equal(keys, ko[order]) and np.array_equal(perm, order), tag
+            sim.deposit()
+            d = sim.density()
+            if n:
+                assert_density(d, O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
+            else:
+                assert not d.any(), tag
+            sim.set_particles(pos, vel, mass)
+            sim.step(dt, 2)
+            x, v = sim.positions(), sim.velocities()
+        xo, vo = pos, vel
+        for _ in range(2):
+            xo, vo = O.pm_step(xo, vo, mass, G, L, dt)
+        assert x.dtype == np.float32 and v.dtype == vdt and x.shape == (n, 3), tag
+        if n:
+            dx = np.abs(x.astype(np.float64) - xo)
+            assert np.minimum(dx, L - dx).max() <= 1e-5 * L, tag
+            assert np.abs(v - vo).max() <= 1e-5 * max(np.abs(vo).max(), 1e-30), tag
+
+
 def test_main_shaped_driver_runs_both_ways():
     """examples/run_collision.py = main.py with the reference's constants and inputs: the loop body call by call through
     pm.functions (reference names, host arrays) and the resident loop give the same energies."""
