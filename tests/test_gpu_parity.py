@@ -624,6 +624,36 @@ def test_random_small_configurations(pm):
             assert np.abs(v - vo).max() <= 1e-5 * max(np.abs(vo).max(), 1e-30), tag
 
 
+def test_random_small_configurations_ngp(pm):
+    """The same for the nearest-grid-point branch (float64 meshes), against the oracle's NumPy restatement."""
+    rng = np.random.default_rng(77)
+    for case in range(16):
+        G = int(rng.choice([2, 3, 5, 8, 16, 17, 32]))
+        L = int(rng.choice([7, 100, 10000]))
+        n = int(rng.choice([1, 2, 65, 257, 3000]))
+        pos = rng.random((n, 3)) * L if case % 3 else (rng.random((n, 3)) - 0.5) * 6 * L
+        if case % 3 == 2:
+            pos = np.full((n, 3), 0.61 * L) + rng.random((n, 3)) * (0.5 * L / G)
+        vel = rng.normal(0, 0.3 * L, (n, 3))
+        mass = (rng.random(n) + 0.5).astype(np.float32)
+        pdt, vdt = [(np.float32, np.float32), (np.float64, np.float64), (np.float32, np.float64), (np.float64, np.float32)][case % 4]
+        pos, vel = pos.astype(pdt), vel.astype(vdt)
+        tag = (case, G, L, n, pdt.__name__, vdt.__name__)
+        try:
+            xo, vo = pos, vel
+            for _ in range(2):
+                xo, vo = O.pm_step_ngp(xo, vo, mass, G, L, 0.01)
+        except IndexError:
+            continue                                    # a position wrapped to exactly L: the reference stops there
+        with pm.Simulation(G, L, pos, vel, mass, interpolation="NGP") as sim:
+            sim.step(0.01, 2)
+            x, v = sim.positions(), sim.velocities()
+        assert x.dtype == np.float32 and v.dtype == vo.dtype, tag
+        dx = np.abs(x.astype(np.float64) - xo)
+        assert np.minimum(dx, L - dx).max() <= 1e-5 * L, tag
+        assert np.abs(v - vo).max() <= 1e-5 * max(np.abs(vo).max(), 1e-30), tag
+
+
 def test_main_shaped_driver_runs_both_ways():
     """examples/run_collision.py = main.py with the reference's constants and inputs: the loop body call by call through
     pm.functions (reference names, host arrays) and the resident loop give the same energies."""
