@@ -198,3 +198,32 @@ def test_slab_without_particles_and_with_arrivals_only():
         sim.step(0.01, 1)
         ids, x, v = sim.particles()
         assert sorted(ids.tolist()) == [7, 8, 9] and np.isfinite(x).all() and np.isfinite(v).all()
+
+
+def test_slab_random_small_configurations_world1():
+    """Random small set-ups through the slab calls (one slab = the whole mesh) against the oracle, three steps each."""
+    from oracle import pm_oracle as O
+    from pm.distributed import SlabSimulation
+    O.build()
+    rng = np.random.default_rng(31)
+    for case in range(12):
+        G = int(rng.choice([4, 6, 8, 12, 16, 24, 32]))
+        L = int(rng.choice([7, 100, 10000]))
+        n = int(rng.choice([1, 2, 65, 257, 3000]))
+        pos = (rng.random((n, 3)) * L).astype(np.float32) if case % 2 else ((rng.random((n, 3)) - 0.5) * 6 * L).astype(np.float32)
+        pos %= np.float32(L)
+        pos[pos >= L] = 0.0
+        vel = rng.normal(0, 0.3 * L, (n, 3)).astype(np.float32)
+        mass = (rng.random(n) + 0.5).astype(np.float32)
+        ids = np.arange(n, dtype=np.uint32)
+        with SlabSimulation(G, L, pos, vel, mass, ids, device_index=0, capacity=n + 64) as sim:
+            sim.step(0.01, 3)
+            i, x, v = sim.particles()
+        xo, vo = pos, vel
+        for _ in range(3):
+            xo, vo = O.pm_step(xo, vo, mass, G, L, 0.01)
+        tag = (case, G, L, n)
+        assert sorted(i.tolist()) == list(range(n)), tag
+        dx = np.abs(x.astype(np.float64) - xo[i])
+        assert np.minimum(dx, L - dx).max() <= 1e-5 * L, tag
+        assert np.abs(v - vo[i]).max() <= 1e-5 * max(np.abs(vo).max(), 1e-30), tag
