@@ -84,15 +84,17 @@ def test_slab_world1_gpu(case, tmp_path):
     check(case, [out])
 
 
-@pytest.mark.parametrize("case", ["g32", "g512"])
-def test_slab_world2_one_gpu(case, tmp_path):
+@pytest.mark.parametrize("case,world", [("g32", 2), ("g512", 2), ("g32", 4), ("g512", 4), ("g512", 8)])
+def test_slab_world_n_one_gpu(case, world, tmp_path):
+    """Several processes on the one GPU of the test box, exchanging over gloo: with two the next and the previous rank
+    are the same one, with four and eight they differ (eight slabs of 64 planes is the layout of the headline run on one node)."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    outs = [str(tmp_path / f"r{r}.npz") for r in range(2)]
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=run_rank, args=(r, 2, port, case, outs[r])) for r in range(2)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, case, outs[r])) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -1,5 +1,5 @@
 """The exchange code of the slab-decomposed step (pm.distributed.SlabSimulation) on CPU: world_size 1 in-process and
-world_size 2 over gloo, each with the oracle-based engine, against the single-process oracle on the same particles.
+world_size 2 and 4 over gloo, each with the oracle-based engine, against the single-process oracle on the same particles.
 Equality is up to float32 rounding: a slab's extra density plane is added to the next slab's plane 0 as one float32 term,
 and the transforms run axis by axis instead of as one 3-D transform."""
 import os
@@ -90,13 +90,16 @@ def test_slab_world1(tmp_path):
     check([out])
 
 
-def test_slab_world2_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_world_n_gloo(tmp_path, world):
+    """world 2: the next and the previous rank are the same one; world 4: they differ, and a particle can cross two
+    slab faces in the K steps."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    outs = [str(tmp_path / f"r{r}.npz") for r in range(2)]
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=run_rank, args=(r, 2, port, outs[r])) for r in range(2)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, outs[r])) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
