@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
                     help="--gpus N > 1: N independent replicas of the workload (default), or ONE run of the workload with the "
                          "mesh cut into N slabs (all-to-all transposes, halo planes and particle migration over RCCL)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="--parallelism slab: torch.distributed backend (gloo stages the exchanges through the host: for "
+                         "rehearsing the multi-rank run on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -296,8 +299,12 @@ def slab_main(args, rank, world, local_rank):
     import torch.distributed as dist
     from pm.distributed import SlabSimulation, slab_of
     torch.cuda.set_device(local_rank)
+    red = "cuda" if args.backend == "nccl" else "cpu"        # where the few scalars reduced below live
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     n, G, L = args.n, args.grid, BOX
     pos, vel, mass = make_workload(args.workload, n, L, 1052)
     mine = slab_of(pos, G, L, world) == rank
@@ -318,16 +325,16 @@ def slab_main(args, rank, world, local_rank):
     sim.step(DT, k_prof)
     phases = sim.phase_times()
     sim.profile = False
-    pt = torch.tensor([phases[p] / k_prof for p in sim.PHASES], dtype=torch.float64, device="cuda")
+    pt = torch.tensor([phases[p] / k_prof for p in sim.PHASES], dtype=torch.float64, device=red)
     if world > 1:
         dist.all_reduce(pt, op=dist.ReduceOp.MAX)
     phases = {p: round(float(v), 4) for p, v in zip(sim.PHASES, pt)}
     loads = [n_local]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-        l = torch.zeros(world, dtype=torch.int64, device="cuda")
+        l = torch.zeros(world, dtype=torch.int64, device=red)
         l[rank] = n_local
         dist.all_reduce(l)
         loads = [int(x) for x in l]
@@ -340,7 +347,7 @@ def slab_main(args, rank, world, local_rank):
             "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {G // world} planes",
-                       "particles_per_slab_at_start": loads},
+                       "particles_per_slab_at_start": loads, "backend": args.backend if world > 1 else None},
             "phases_ms": phases,
             "roofline": {"bound": "hbm", "kernel": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None, "algorithmic_bytes_per_launch": b_step,
