@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--no-fused-gradient", action="store_true")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    ap.add_argument("--also-uniform", action="store_true",
+                    help="one GPU, default workload: also time the uniform particle set of the same size (reported as "
+                         "`uniform_set` in the same line)")
     ap.add_argument("--no-slab-probe", action="store_true",
                     help="--gpus N > 1 in replica mode: do not also run the slab-decomposed step in child processes")
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
@@ -219,6 +222,21 @@ def main():
     sim.set_flags(timing=False, fused_gradient=fused)
 
     sim.close()
+    # beside the headline: the uniform particle set of the same size on the same mesh (one GPU, default workload only)
+    also = None
+    if world == 1 and args.workload == "two_galaxy" and args.also_uniform:
+        up, uv, um = make_workload("uniform", n, L, 1052)
+        with pm.Simulation(G, L, up, uv, um, device=local_rank, fused_gradient=fused) as usim:
+            usim.step(DT, args.warmup)
+            usim.synchronize()
+            t0 = time.perf_counter()
+            usim.step(DT, args.steps)
+            usim.synchronize()
+            ue = time.perf_counter() - t0
+        also = {"workload": f"uniform N={n} G={G} L={L} dt={DT}", "value": n * args.steps / ue, "unit": "particle-updates/s",
+                "ms_per_step": ue / args.steps * 1e3,
+                "step_roofline_frac": (64 * n + 80 * m) / (ue / args.steps) / 1e9 / HBM_PEAK_GBPS}
+        del up, uv, um
     slab = None
     if world > 1 and not args.no_slab_probe:
         slab = slab_probe(args, rank, world, dist)
@@ -256,6 +274,8 @@ def main():
         }
         if args.cpu_baseline == "auto" and world == 1:
             out["cpu_baseline"] = cpu_baseline(pos, vel, mass, G, L, DT)
+        if also is not None:
+            out["uniform_set"] = also
         if slab is not None:
             out["slab_decomposed"] = slab
         print(json.dumps(out), flush=True)
