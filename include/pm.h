@@ -43,7 +43,7 @@ enum { PM_MESH_DENSITY = 0, PM_MESH_POTENTIAL = 1, PM_MESH_GX = 2, PM_MESH_GY = 
 enum {
     PM_FLAG_TIMING = 1u,      /* record HIP events around every stage (pm_stage_times) */
     PM_FLAG_FUSED_GRADIENT = 2u, /* pm_step keeps intermediate meshes on chip where it can: the potential is differenced
-                                    inside the gather (no gx,gy,gz), and at grid_size 512 the deposit emits each density
+                                    inside the gather (no gx,gy,gz), and at grid_size 512 or 1024 the deposit emits each density
                                     row already transformed along z (no density mesh) */
     PM_FLAG_NGP = 8u,         /* pm_create only: pm_step runs the nearest-grid-point branch (CIC_interpolation = False,
                                  main.py:9, 40-41), whose meshes and forces are float64 */
