@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--also-uniform", action="store_true",
                     help="one GPU, default workload: also time the uniform particle set of the same size (reported as "
                          "`uniform_set` in the same line)")
+    ap.add_argument("--device-ic", action="store_true",
+                    help="draw the workload on the GPU (pm_generate: same distributions, a counter-based random stream) "
+                         "instead of building it with NumPy on the host; meant for the 64M+ particle configurations")
     ap.add_argument("--no-slab-probe", action="store_true",
                     help="--gpus N > 1 in replica mode: do not also run the slab-decomposed step in child processes")
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
@@ -194,9 +197,16 @@ def main():
     m = G ** 3
     # every rank holds an independent replica of the workload (its own seed); --parallelism slab runs ONE
     # simulation over the ranks instead, and slab_probe() below reports that run beside this one
-    pos, vel, mass = make_workload(args.workload, n, L, 1052 + rank)
     fused = not args.no_fused_gradient
-    sim = pm.Simulation(G, L, pos, vel, mass, device=local_rank, fused_gradient=fused)
+    if args.device_ic:
+        sim = pm.Simulation(G, L, capacity=n, device=local_rank, fused_gradient=fused)
+        sim.generate(args.workload, n, 1052 + rank)
+        pos = vel = mass = None
+        if args.cpu_baseline == "auto" and world == 1:
+            pos, vel, mass = sim.positions(), sim.velocities(), np.ones(n, np.float32)
+    else:
+        pos, vel, mass = make_workload(args.workload, n, L, 1052 + rank)
+        sim = pm.Simulation(G, L, pos, vel, mass, device=local_rank, fused_gradient=fused)
 
     def barrier():
         if dist is not None:
@@ -261,7 +271,7 @@ def main():
             "value": world * n * args.steps / elapsed, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic (drawn on the device)" if args.device_ic else "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "fused_gradient": fused,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

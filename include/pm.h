@@ -69,6 +69,23 @@ void pm_destroy(pm_ctx *ctx);
 int pm_set_particles(pm_ctx *ctx, const void *pos, int pos_dtype, const void *vel, int vel_dtype,
                      const float *mass, int64_t n);
 
+/* Synthetic particle sets drawn on the device into the context (float32 positions and velocities, unit masses), in
+ * place of pm_set_particles: the sets of 10^7 .. 10^9 particles the engine is measured on need not be built and
+ * shipped from the host.  The distributions are those of the reference's generators, not their random streams:
+ *   PM_IC_UNIFORM     positions uniform in the box.                                    params: sigma_v
+ *   PM_IC_TWO_GALAXY  two Plummer spheres rho ~ (1 + r^2/a^2)^-5/2 (galaxy_generation_functions.py:267-288) truncated
+ *                     at rmax, n/2 particles about centre1 and the rest about centre2, each moving with half of the
+ *                     relative velocity (zero total momentum, functions.py:320-338).
+ *                     params: a1, a2, rmax, centre1[3], centre2[3], relative_velocity[3], sigma_v
+ *   PM_IC_DISK        exponential disk rho ~ exp(-R/Rd) exp(-|z|/z0): R ~ Gamma(2, Rd) truncated at Rmax, z ~
+ *                     Laplace(0, z0) truncated at zmax, uniform azimuth (galaxy_generation_functions.py:97-136).
+ *                     params: Rd, z0, Rmax, zmax, centre[3], sigma_v
+ * Every set adds an isotropic Gaussian velocity of dispersion sigma_v per axis; positions are wrapped into the box as
+ * main.py:60 wraps them.  Particle p draws from Philox4x32-10 with counter (p, purpose, attempt) and key seed, so the
+ * set depends on (kind, n, seed, params) only.  nparams must be the count listed for the kind. */
+enum { PM_IC_UNIFORM = 0, PM_IC_TWO_GALAXY = 1, PM_IC_DISK = 2 };
+int pm_generate(pm_ctx *ctx, int kind, int64_t n, uint64_t seed, const double *params, int nparams);
+
 /* density_func(positions, grid_size, box_size, masses), the CIC branch:
  * functions.py:19-70, call site main.py:50. */
 int pm_deposit(pm_ctx *ctx);

@@ -329,6 +329,32 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     return PM_OK;
 }
 
+int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params, int nparams)
+{
+    if (!c) return PM_EINVAL;
+    if (c->slab) return fail(c, PM_ESTATE, "pm_generate fills a whole-mesh context: a slab takes its share through pm_slab_set_particles");
+    const int want = pm_generate_param_count(kind);
+    if (want < 0) return fail(c, PM_EINVAL, "kind must be PM_IC_UNIFORM, PM_IC_TWO_GALAXY or PM_IC_DISK");
+    if (n < 0 || n > c->cap) return fail(c, PM_EINVAL, "n outside [0, n_capacity]");
+    if (!params || nparams != want) return fail(c, PM_EINVAL, "this kind takes " + std::to_string(want) + " parameters");
+    for (int k = 0; k < want; ++k)
+        if (!std::isfinite(params[k])) return fail(c, PM_EINVAL, "parameter " + std::to_string(k) + " is not finite");
+    // scale lengths and truncation radii must be positive (the rejection loops rely on it), dispersions non-negative
+    const int npos = kind == PM_IC_TWO_GALAXY ? 3 : kind == PM_IC_DISK ? 4 : 0;
+    for (int k = 0; k < npos; ++k)
+        if (!(params[k] > 0.0)) return fail(c, PM_EINVAL, "parameter " + std::to_string(k) + " (a length) must be positive");
+    if (params[want - 1] < 0.0) return fail(c, PM_EINVAL, "sigma_v must not be negative");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pos_in_f64 = c->pos_f64 = false;
+    c->vel_f64 = false;
+    TRY(alloc_particles(c));
+    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false;
+    HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
 static int deposit_impl(pm_ctx *c, bool to_spectrum)
 {
     TRY(whole_mesh(c));

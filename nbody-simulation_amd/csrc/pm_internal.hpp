@@ -158,6 +158,9 @@ pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int
 // stage -> records: positions (n,3) of the given dtype + masses (or ones), velocities (or zeros) + iota ids
 hipError_t pm_launch_pack(pm_ctx *c, const void *pos_aos, const float *mass, const void *vel_aos);
 hipError_t pm_launch_cell_keys(pm_ctx *c);
+// synthetic sets drawn on the device into the live float32 records; the number of parameters a kind takes (-1: no such kind)
+hipError_t pm_launch_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params);
+int pm_generate_param_count(int kind);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);
 hipError_t pm_sort_fill_iota(pm_ctx *c);      // c->iota[r] = r, once per context
 size_t pm_sort_tmp_bytes(int64_t cap);

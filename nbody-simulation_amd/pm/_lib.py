@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PM_LIBRARY") or os.path.join(os.path.dirname(_HERE), 
 PM_F32, PM_F64 = 0, 1
 MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ = range(5)
 FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP = 1, 2, 4, 8
+IC_KINDS = {"uniform": 0, "two_galaxy": 1, "disk": 2}
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
 
 _c_p = ctypes.c_void_p
@@ -25,6 +26,7 @@ SIGNATURES = {
     "pm_create": (_c_p, [_int, _dbl, _i64, _int, ctypes.c_uint]),
     "pm_destroy": (None, [_c_p]),
     "pm_set_particles": (_int, [_c_p, _c_p, _int, _c_p, _int, _c_p, _i64]),
+    "pm_generate": (_int, [_c_p, _int, _i64, ctypes.c_uint64, _c_p, _int]),
     "pm_deposit": (_int, [_c_p]),
     "pm_potential": (_int, [_c_p]),
     "pm_gradient": (_int, [_c_p]),

@@ -5,6 +5,35 @@ import numpy as np
 from . import _lib as L
 
 
+def ic_parameters(kind, box_size, **over):
+    """Parameter list of pm_generate for a kind, defaults as fractions of the box size, overridden by name."""
+    c = 0.5 * box_size
+    if kind == "uniform":
+        d = {"sigma_v": 10.0}
+    elif kind == "two_galaxy":
+        u = np.array([0.67, 0.33, 0.0])
+        u /= np.linalg.norm(u)
+        d = {"a1": 0.02 * box_size, "a2": 0.05 * box_size, "rmax": 0.45 * box_size, "centre1": c - 0.1 * box_size * u,
+             "centre2": c + 0.1 * box_size * u, "relative_velocity": (-3000.0, 300.0, 0.0), "sigma_v": 10.0}
+    elif kind == "disk":
+        d = {"Rd": 0.03 * box_size, "z0": 0.003 * box_size, "Rmax": None, "zmax": None, "centre": (c, c, c), "sigma_v": 10.0}
+    else:
+        raise ValueError(f"kind must be 'uniform', 'two_galaxy' or 'disk', got {kind!r}")
+    unknown = set(over) - set(d)
+    if unknown:
+        raise TypeError(f"{kind}: no parameter named {sorted(unknown)}; it takes {list(d)}")
+    d.update(over)
+    if kind == "disk":          # galaxy_generation_functions.py:107-108
+        if d["Rmax"] is None:
+            d["Rmax"] = 5.0 * d["Rd"]
+        if d["zmax"] is None:
+            d["zmax"] = 5.0 * d["z0"]
+    out = []
+    for v in d.values():
+        out.extend(np.ravel(np.asarray(v, dtype=np.float64)).tolist())
+    return out
+
+
 class Simulation:
     """grid_size / box_size / dt are the module constants of main.py:5-7; positions, velocities
     and masses are the bare arrays of main.py:25-33, in their dtypes (float32 or float64)."""
@@ -57,6 +86,19 @@ class Simulation:
         self._ck(self.lib.pm_set_particles(self.ctx, L.ptr(x), L.PM_F64 if x.dtype == np.float64 else L.PM_F32,
                                            L.ptr(v), L.PM_F64 if self._vel_dtype == np.float64 else L.PM_F32,
                                            L.ptr(m), len(x)))
+
+    def generate(self, kind, n, seed=0, **params):
+        """Draw a synthetic particle set on the device in place of set_particles (pm_generate): "uniform",
+        "two_galaxy" (two truncated Plummer spheres on a collision course about the box centre, as main.py:28-33
+        places its two galaxies) or "disk" (exponential disk).  Lengths default to fixed fractions of the box;
+        keyword arguments override them:
+          uniform:    sigma_v
+          two_galaxy: a1, a2, rmax, centre1, centre2, relative_velocity, sigma_v
+          disk:       Rd, z0, Rmax, zmax, centre, sigma_v"""
+        q = ic_parameters(kind, float(self.box_size), **params)
+        arr = np.asarray(q, dtype=np.float64)
+        self._vel_dtype = np.float32
+        self._ck(self.lib.pm_generate(self.ctx, L.IC_KINDS[kind], int(n), int(seed) & (2 ** 64 - 1), L.ptr(arr), len(arr)))
 
     # ---- stages ------------------------------------------------------------------------
     def deposit(self):
