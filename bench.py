@@ -168,7 +168,7 @@ def main():
                     help="--gpus N > 1: N independent replicas of the workload (default), or ONE run of the workload with the "
                          "mesh cut into N slabs (all-to-all transposes, halo planes and particle migration over RCCL)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="--parallelism slab: torch.distributed backend (gloo stages the exchanges through the host: for "
+                    help="--parallelism slab (and the slab probe of a replica run): torch.distributed backend (gloo stages the exchanges through the host: for "
                          "rehearsing the multi-rank run on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
@@ -301,8 +301,13 @@ def slab_probe(args, rank, world, dist):
     import subprocess
     env = dict(os.environ)
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 29)
+    # the children make a rendezvous of their own (rank 0's child hosts the store on that port).  The launcher's
+    # TORCHELASTIC_* variables would turn every child into a client of the launcher's store, which does not listen there.
+    for k in [k for k in env if k.startswith("TORCHELASTIC")]:
+        del env[k]
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 10)), "--warmup", "2",
-           "--parallelism", "slab", "--workload", args.workload, "--particles", str(args.n), "--grid", str(args.grid)]
+           "--parallelism", "slab", "--workload", args.workload, "--particles", str(args.n), "--grid", str(args.grid),
+           "--backend", args.backend]
     dist.barrier()
     if rank == 0:
         print("bench: replica measurement done; probing the slab-decomposed step in child processes (at most 100 s)", file=sys.stderr, flush=True)
