@@ -91,6 +91,13 @@ int pm_generate(pm_ctx *ctx, int kind, int64_t n, uint64_t seed, const double *p
 int pm_deposit(pm_ctx *ctx);
 /* compute_potential(density, grid_size): functions.py:73-89, call site main.py:51. */
 int pm_potential(pm_ctx *ctx);
+/* Optional Gaussian softening of the Poisson solve: the Green's function becomes 1/k^2 * exp(-(sigma k_phys)^2 / 2),
+ * i.e. the density is smoothed with a Gaussian of standard deviation `length` (in the units of box_size) before the
+ * potential is taken; k_phys = 2 pi k G / box_size for the k of functions.py:75.  The reference has no softening
+ * (functions.py:85 divides by the bare k^2): length = 0, the default, is the reference's solve bit for bit, and any
+ * other value leaves its results.  Applies to every solve of the context from the next call on (pm_potential, pm_step,
+ * pm_run, the float64 solve of the NGP branch, pm_slab_solve_x). */
+int pm_set_softening(pm_ctx *ctx, double length);
 /* np.gradient(potential): call site main.py:54. */
 int pm_gradient(pm_ctx *ctx);
 /* force_func(potential_gradient, positions, grid_size, box_size), the CIC

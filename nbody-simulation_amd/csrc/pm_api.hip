@@ -427,6 +427,16 @@ static int potential_impl(pm_ctx *c, bool have_z)
 
 int pm_potential(pm_ctx *c) { return potential_impl(c, false); }
 
+int pm_set_softening(pm_ctx *c, double length)
+{
+    if (!c) return PM_EINVAL;
+    if (!(length >= 0.0) || !std::isfinite(length)) return fail(c, PM_EINVAL, "softening length must be finite and not negative");
+    // exp(-(sigma k_phys)^2 / 2) with k_phys = 2 pi k G / L, as a coefficient of k^2 in (cycles/sample)^2
+    const double a = 2.0 * 3.14159265358979323846 * length * (double)c->g.G / c->g.L;
+    c->g.soft = (float)(0.5 * a * a);
+    return PM_OK;
+}
+
 int pm_gradient(pm_ctx *c)
 {
     TRY(whole_mesh(c));

@@ -190,7 +190,7 @@ __device__ __forceinline__ float freq32(int a, int G, double invG)
 
 // potential_k = density_k / k2 (functions.py:85): k2 = kx**2 + ky**2 + kz**2 in float32, and NumPy divides a
 // complex128 by it as a multiplication by 1.0 / k2; the 1/M of ifftn (functions.py:89) goes in here too.
-__global__ void k_green64(double2 *__restrict__ S, int G, int Gh, double invM)
+__global__ void k_green64(double2 *__restrict__ S, int G, int Gh, double invM, double soft)
 {
     const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (q >= (int64_t)G * G * Gh) return;
@@ -200,7 +200,11 @@ __global__ void k_green64(double2 *__restrict__ S, int G, int Gh, double invM)
     const float k2 = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), __fmul_rn(ky, ky)), __fmul_rn(kz, kz));
     double2 v = S[q];
     if ((i | j | c) == 0) v = make_double2(0.0, 0.0);                   // functions.py:86
-    else { const double r = 1.0 / (double)k2; v.x = v.x * r * invM; v.y = v.y * r * invM; }
+    else {
+        double r = 1.0 / (double)k2;
+        if (soft != 0.0) r *= exp(-soft * (double)k2);
+        v.x = v.x * r * invM; v.y = v.y * r * invM;
+    }
     S[q] = v;
 }
 
@@ -321,7 +325,7 @@ hipError_t pm_launch_ngp_sum(pm_ctx *c)
 hipError_t pm_launch_green64(pm_ctx *c)
 {
     const int G = c->g.G, Gh = c->g.Gh;
-    k_green64<<<grid_for((int64_t)G * G * Gh), BLOCK, 0, c->stream>>>(c->spectrum64, G, Gh, 1.0 / (double)c->g.M);
+    k_green64<<<grid_for((int64_t)G * G * Gh), BLOCK, 0, c->stream>>>(c->spectrum64, G, Gh, 1.0 / (double)c->g.M, (double)c->g.soft);
     return hipGetLastError();
 }
 

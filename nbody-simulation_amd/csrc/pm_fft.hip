@@ -45,6 +45,7 @@ struct col_pass {
     int ncols;              // valid columns per outer index (G/2 + 1)
     int G;
     float invM;
+    float soft;                 // pm_geom::soft
     int outer0;             // mesh index of outer index 0 (Green multiply)
     int tile0;              // first column tile of this launch (a launch may cover a range of tiles only)
     int ntiles;             // column tiles per outer index in this launch
@@ -201,6 +202,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
                 float kx = freq(a, G, invG);
                 float k2 = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), kyz), __fmul_rn(kz, kz));
                 float scl = ((a | yy | col) == 0) ? 0.0f : __fmul_rn(__frcp_rn(k2), p.invM);
+                if (p.soft != 0.0f) scl *= expf(-p.soft * k2);
                 v[b * 8 + r].x *= scl; v[b * 8 + r].y *= scl;
             }
         if constexpr (R1 != 8) {
@@ -385,6 +387,7 @@ static col_pass pass_for(pm_ctx *c, float2 *spec)
     col_pass p{};
     p.spec = spec; p.G = G; p.ncols = G / 2 + 1; p.tiles = P / COLS; p.tile0 = 0; p.ntiles = p.tiles;
     p.invM = (float)(1.0 / (double)c->g.M);
+    p.soft = c->g.soft;
     return p;
 }
 

@@ -25,6 +25,7 @@ struct pm_geom {
     int Gd;         // planes the deposit writes: G (periodic along i), or Gs + 1 (the last one belongs to the next slab)
     int lo;         // planes of the potential buffer below plane i0 (0, or 1 in a slab)
     int sb;         // half spectrum: rows of 2^sb neighbouring planes are interleaved (pm_spec_row); 0 = plain (i, j) order
+    float soft;     // Gaussian softening: the Green's function is 1/k2 * exp(-soft * k2), k2 in (cycles/sample)^2; 0 = the bare 1/k2 of functions.py:85
 };
 
 // Row (i, j) of the half spectrum is row pm_spec_row(...) of the buffer (times the pitch).  With sb = 0 that is

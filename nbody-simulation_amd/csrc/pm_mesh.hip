@@ -33,6 +33,7 @@ __global__ void k_green(float2 *__restrict__ spec, pm_geom g, float invM)
         v.x = 0.0f; v.y = 0.0f;
     } else {
         float scl = 1.0f / k2;
+        if (g.soft != 0.0f) scl *= expf(-g.soft * k2);
         v.x = (v.x * scl) * invM;
         v.y = (v.y * scl) * invM;
     }
@@ -74,6 +75,7 @@ __global__ void k_green_t(float2 *__restrict__ spec, pm_geom g, float invM, int 
         v.x = 0.0f; v.y = 0.0f;
     } else {
         float scl = 1.0f / k2;
+        if (g.soft != 0.0f) scl *= expf(-g.soft * k2);
         v.x = (v.x * scl) * invM;
         v.y = (v.y * scl) * invM;
     }

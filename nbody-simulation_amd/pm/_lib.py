@@ -29,6 +29,7 @@ SIGNATURES = {
     "pm_generate": (_int, [_c_p, _int, _i64, ctypes.c_uint64, _c_p, _int]),
     "pm_deposit": (_int, [_c_p]),
     "pm_potential": (_int, [_c_p]),
+    "pm_set_softening": (_int, [_c_p, _dbl]),
     "pm_gradient": (_int, [_c_p]),
     "pm_forces": (_int, [_c_p]),
     "pm_gather_kick_drift": (_int, [_c_p, _dbl]),

@@ -76,6 +76,10 @@ class HipSlabEngine:
             raise ValueError("more particles than the engine's capacity")
         self._check(self.lib.pm_slab_set_particles(self.ctx, pos.ctypes.data, vel.ctypes.data, mass.ctypes.data, ids.ctypes.data, len(pos)))
 
+    def set_softening(self, length):
+        """Gaussian softening of the solve along x (pm_set_softening); every rank must set the same length."""
+        self._check(self.lib.pm_set_softening(self.ctx, float(length)))
+
     def deposit(self):
         self._check(self.lib.pm_slab_deposit(self.ctx))
 

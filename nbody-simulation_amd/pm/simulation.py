@@ -107,6 +107,11 @@ class Simulation:
     def solve_potential(self):
         self._ck(self.lib.pm_potential(self.ctx))
 
+    def set_softening(self, length):
+        """Gaussian softening of the Poisson solve (pm_set_softening): the density is smoothed over `length` (units of
+        box_size) before the potential is taken.  0, the default, is the reference's bare 1/k^2 (functions.py:85)."""
+        self._ck(self.lib.pm_set_softening(self.ctx, float(length)))
+
     def gradient(self):
         self._ck(self.lib.pm_gradient(self.ctx))
 

@@ -90,8 +90,16 @@ def CIC_f64(positions, grid_size, box_size, masses):
     return d
 
 
-def compute_potential(density, grid_size):
-    """functions.py:73-89.  k in cycles/sample, +delta_k/k^2, DC zeroed, full complex64 FFT."""
+def softening_coefficient(length, grid_size, box_size):
+    """Coefficient c of exp(-c k2) for a Gaussian softening length in box units (pm_set_softening; not in the reference):
+    exp(-(length k_phys)^2 / 2), k_phys = 2 pi k G / L, rounded to float32 as the library holds it."""
+    a = 2.0 * np.pi * float(length) * grid_size / float(box_size)
+    return np.float32(0.5 * a * a)
+
+
+def compute_potential(density, grid_size, soft=0.0):
+    """functions.py:73-89.  k in cycles/sample, +delta_k/k^2, DC zeroed, full complex64 FFT.  soft != 0 (an extension,
+    see softening_coefficient) multiplies the spectrum by exp(-soft k2) as well."""
     n = grid_size
     j = np.arange(n)
     j = np.where(j < (n + 1) // 2, j, j - n)
@@ -102,6 +110,11 @@ def compute_potential(density, grid_size):
     mean = np.mean(density)                                 # :81
     dk = _sfft.fftn(density - mean)                         # :82
     pk = dk / k2                                            # :85
+    if soft:
+        if pk.dtype == np.complex64:
+            pk = pk * np.exp(-np.float32(soft) * k2)
+        else:
+            pk = pk * np.exp(-np.float64(np.float32(soft)) * k2.astype(np.float64))
     pk[0, 0, 0] = 0.0                                       # :86
     return np.real(_sfft.ifftn(pk))                         # :89
 

@@ -690,3 +690,83 @@ def test_errors(pm):
         assert not sim.density().any()
         with pytest.raises(pm.PMError):
             sim.forces()                                    # pm_forces not called
+
+
+# ---- optional softening of the solve (pm_set_softening; the reference has none) -----------------
+
+def _blob_density(G, seed):
+    rng = np.random.default_rng(seed)
+    n = 20000
+    pos = (np.float32(0.5 * 10000) + rng.normal(0, 600, (n, 3))).astype(np.float32) % np.float32(10000)
+    return pos, O.CIC(pos, G, 10000, np.ones(n, np.float32))
+
+
+@pytest.mark.parametrize("cells", [0.75, 2.0])
+def test_softened_potential_against_oracle(pm, cells):
+    G, L = 32, 10000
+    pos, dens = _blob_density(G, 3)
+    length = cells * L / G
+    ref = O.compute_potential(dens, G, soft=O.softening_coefficient(length, G, L))
+    bare = O.compute_potential(dens, G)
+    assert np.abs(ref - bare).max() > 0.05 * np.abs(bare).max()          # the softening does something
+    with pm.Simulation(G, L, pos, None, None) as sim:
+        sim.set_softening(length)
+        sim.set_mesh(0, dens)
+        sim.solve_potential()
+        phi = sim.potential()
+        assert np.abs(phi - ref).max() <= 1e-5 * np.abs(ref).max()
+        # length 0 restores the reference's solve bit for bit
+        sim.set_softening(0.0)
+        sim.solve_potential()
+        again = sim.potential()
+    with pm.Simulation(G, L, pos, None, None) as sim:
+        sim.set_mesh(0, dens)
+        sim.solve_potential()
+        assert np.array_equal(sim.potential(), again)
+    with pytest.raises(pm.PMError, match="softening"):
+        with pm.Simulation(G, L, pos, None, None) as sim:
+            sim.set_softening(-1.0)
+
+
+def test_softened_potential_hand_written_transforms_match_rocfft(pm):
+    # G = 512: the fused forward-x / Green / inverse-x pass against rocFFT's 3-D plans around the plain multiply, and
+    # the fused step (spectrum rows straight from the deposit) against the staged one
+    G, L, n = 512, 10000, 200_000
+    rng = np.random.default_rng(11)
+    pos = (np.float32(5000) + rng.normal(0, 400, (n, 3))).astype(np.float32) % np.float32(L)
+    vel = rng.normal(0, 10, (n, 3)).astype(np.float32)
+    length = 1.5 * L / G
+    out = []
+    for rocfft_only in (False, True):
+        with pm.Simulation(G, L, pos, vel, None, rocfft_only=rocfft_only) as sim:
+            sim.set_softening(length)
+            sim.deposit()
+            sim.solve_potential()
+            out.append(sim.potential())
+    assert np.abs(out[0] - out[1]).max() <= 1e-5 * np.abs(out[1]).max()
+    with pm.Simulation(G, L, pos, vel, None) as sim:
+        sim.deposit()
+        sim.solve_potential()
+        bare = sim.potential()
+    assert np.abs(out[0] - bare).max() > 0.002 * np.abs(bare).max()     # a blob 20 cells wide: 0.4 % at its centre
+    res = []
+    for fused in (True, False):
+        with pm.Simulation(G, L, pos, vel, None, fused_gradient=fused) as sim:
+            sim.set_softening(length)
+            sim.step(0.005, 2)
+            res.append((sim.positions(), sim.velocities()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_softened_ngp_branch_against_oracle(pm):
+    G, L = 32, 10000
+    pos, _ = _blob_density(G, 5)
+    dens = O.NGP(pos, G, L, np.ones(len(pos), np.float32))
+    length = 1.25 * L / G
+    ref = O.compute_potential(dens, G, soft=O.softening_coefficient(length, G, L))
+    assert ref.dtype == np.float64
+    with pm.Simulation(G, L, pos, None, None, interpolation="NGP") as sim:
+        sim.set_softening(length)
+        sim.set_mesh_f64(0, dens)
+        sim.solve_potential_f64()
+        assert np.abs(sim.mesh_f64(1) - ref).max() <= 1e-12 * np.abs(ref).max()

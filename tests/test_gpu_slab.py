@@ -31,16 +31,17 @@ CASES = {"g32": dict(G=32, L=100, n=20000, dt=0.002, K=5, crowd=0.48),        # 
          "g1024": dict(G=1024, L=10000, n=200000, dt=0.0005, K=2, crowd=0.49)}  # ... with 8-column tiles along x
 
 
-def single_context(case):
+def single_context(case, softening=0.0):
     import pm
     c = CASES[case]
     pos, vel, mass = make(c["n"], c["L"], 3, c["crowd"])
     with pm.Simulation(c["G"], c["L"], pos, vel, mass, fused_gradient=True) as sim:
+        sim.set_softening(softening)
         sim.step(c["dt"], c["K"])
         return sim.positions(), sim.velocities()
 
 
-def run_rank(rank, world, port, case, out):
+def run_rank(rank, world, port, case, out, softening=0.0):
     import torch.distributed as dist
     from pm.distributed import SlabSimulation, slab_of
     c = CASES[case]
@@ -51,6 +52,7 @@ def run_rank(rank, world, port, case, out):
     ids = np.arange(c["n"], dtype=np.uint32)
     with SlabSimulation(c["G"], c["L"], pos[mine], vel[mine], mass[mine], ids[mine], device_index=0, capacity=c["n"]) as sim:
         start = set(sim.particles()[0].tolist())
+        sim.engine.set_softening(softening)
         sim.step(c["dt"], c["K"])
         i, x, v = sim.particles()
     np.savez(out, ids=i, pos=x, vel=v, moved=len(start - set(i.tolist())))
@@ -59,9 +61,9 @@ def run_rank(rank, world, port, case, out):
         dist.destroy_process_group()
 
 
-def check(case, files):
+def check(case, files, softening=0.0):
     c = CASES[case]
-    xr, vr = single_context(case)
+    xr, vr = single_context(case, softening)
     seen = np.zeros(c["n"], bool)
     moved = 0
     for f in files:
@@ -101,6 +103,29 @@ def test_slab_world_n_one_gpu(case, world, tmp_path):
         p.join(200)
         assert p.exitcode == 0
     assert check(case, outs) > 50
+
+
+@pytest.mark.parametrize("case", ["g32", "g512"])
+def test_slab_softened_solve_two_ranks(case, tmp_path):
+    """pm_set_softening on slab contexts (the solve along x sees only a range of ky per rank): two processes against the
+    softened one-context run, and the softening changes the result."""
+    import torch.multiprocessing as mp
+    c = CASES[case]
+    soft = 4.0 * c["L"] / c["G"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(2)]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=run_rank, args=(r, 2, port, case, outs[r], soft)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+        assert p.exitcode == 0
+    check(case, outs, soft)
+    bare, softened = single_context(case)[1], single_context(case, soft)[1]
+    assert np.abs(bare - softened).max() > 2 * 1e-5 * np.abs(bare).max()      # outside what check() tolerates
 
 
 def _rccl_single_rank(port, out):

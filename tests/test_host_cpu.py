@@ -97,3 +97,19 @@ def test_galaxy_classes():
     assert generate_galaxy("disk", "importance", 5, M_tot=2.5).M_tot == 2.5
     with pytest.raises(ValueError):
         generate_galaxy("ellipse", "importance", 10)
+
+
+def test_oracle_softening_is_a_gaussian_smoothing_of_the_density():
+    # exp(-soft k2) in the solve == the bare solve of the density convolved with a periodic Gaussian of that width
+    from scipy.ndimage import gaussian_filter
+    from oracle import pm_oracle as O
+    G, L, cells = 32, 10000.0, 1.5
+    rng = np.random.default_rng(2)
+    dens = rng.random((G, G, G)).astype(np.float32) ** 8
+    soft = O.softening_coefficient(cells * L / G, G, L)
+    assert soft == np.float32(0.5 * (2 * np.pi * cells) ** 2)
+    a = O.compute_potential(dens, G, soft=soft)
+    b = O.compute_potential(gaussian_filter(dens.astype(np.float64), cells, mode="wrap", truncate=8.0).astype(np.float32), G)
+    assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+    assert np.abs(a - O.compute_potential(dens, G)).max() > 0.05 * np.abs(a).max()
+    assert np.array_equal(O.compute_potential(dens, G, soft=0.0), O.compute_potential(dens, G))

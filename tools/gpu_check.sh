@@ -8,7 +8,7 @@ tail -3 gpurun_out/t.log
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r -- python $R/bench.py --steps 10 --warmup 2 --cpu-baseline skip > $R/gpurun_out/b.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r -- python $R/bench.py --steps 10 --warmup 2 --cpu-baseline skip --no-uniform > $R/gpurun_out/b.log 2>&1 || exit 1
 cd $R
-timeout -k 10 150 python bench.py --steps 20 --warmup 3 --cpu-baseline skip >> gpurun_out/b.log 2>&1 || exit 1
-timeout -k 10 150 python bench.py --steps 20 --warmup 3 --cpu-baseline skip --workload uniform >> gpurun_out/b.log 2>&1 || exit 1
+timeout -k 10 150 python bench.py --steps 20 --warmup 3 --cpu-baseline skip --no-uniform >> gpurun_out/b.log 2>&1 || exit 1
+timeout -k 10 150 python bench.py --steps 20 --warmup 3 --cpu-baseline skip --no-uniform --workload uniform >> gpurun_out/b.log 2>&1 || exit 1

@@ -6,6 +6,6 @@ rc=$?
 tail -5 gpurun_out/tg.log
 [ $rc -ne 0 ] && exit $rc
 ( time timeout -k 10 400 python bench.py ) > gpurun_out/bench_default.log 2>&1 || exit 1
-timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-baseline skip --device-ic --workload disk --n 67108864 --grid 1024 > gpurun_out/bench_disk_device_ic.log 2>&1 || exit 1
-timeout -k 10 300 python bench.py --steps 20 --warmup 3 --cpu-baseline skip --device-ic > gpurun_out/bench_device_ic.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-baseline skip --no-uniform --device-ic --workload disk --n 67108864 --grid 1024 > gpurun_out/bench_disk_device_ic.log 2>&1 || exit 1
+timeout -k 10 300 python bench.py --steps 20 --warmup 3 --cpu-baseline skip --no-uniform --device-ic > gpurun_out/bench_device_ic.log 2>&1 || exit 1
 tail -c 600 gpurun_out/bench_default.log
