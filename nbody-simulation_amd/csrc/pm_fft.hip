@@ -91,7 +91,9 @@ template <int N, int DIR, bool GREEN> struct col_plan {
 // (radix R1, no twiddles) takes butterflies j = jl + TPC b and rows j + 64 r; stages 2 and 3 (radix 8)
 // take j = jl + TPC b and rows j + (N/8) r.  After stage 3 the thread holds the rows jl + TPC m, m < EPT:
 // exactly the inputs of its stage-1 butterflies, which is what lets the Green pass turn round in registers.
-// BLK = 1: the results go to p.blocks instead of back to p.spec; BLK = 2: the inputs come from p.blocks.
+// BLK = 1: the results go to p.blocks instead of back to p.spec; BLK = 2: the inputs come from p.blocks; BLK = 3 (Green
+// pass only): the multiply includes the Gaussian softening factor exp(-p.soft k2) -- an instantiation of its own, so that
+// the pass without softening stays the code it was (as a run-time branch the factor cost that pass 6 %).
 template <int N, int DIR, bool GREEN, int BLK = 0>
 __global__ void __launch_bounds__((col_plan<N, DIR, GREEN>::THREADS))
 k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
@@ -116,7 +118,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
         return g[(int64_t)(row >> p.r_shift) * p.r_hi + (int64_t)(row & ((1 << p.r_shift) - 1)) * p.r_lo];
     };
     // the same column in the all-to-all buffer: plane `outer`'s rows of block b start at (b * Gs + outer) * Gs * pitch
-    float2 *gb = BLK ? p.blocks + ((int64_t)outer << p.gs_shift) * p.row_stride + col : nullptr;
+    float2 *gb = (BLK == 1 || BLK == 2) ? p.blocks + ((int64_t)outer << p.gs_shift) * p.row_stride + col : nullptr;
     auto in_blocks = [&](int row) -> float2 & {
         return gb[(int64_t)(row >> p.gs_shift) * p.block_stride + (int64_t)(row & ((1 << p.gs_shift) - 1)) * p.row_stride];
     };
@@ -202,7 +204,7 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
                 float kx = freq(a, G, invG);
                 float k2 = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), kyz), __fmul_rn(kz, kz));
                 float scl = ((a | yy | col) == 0) ? 0.0f : __fmul_rn(__frcp_rn(k2), p.invM);
-                if (p.soft != 0.0f) scl *= expf(-p.soft * k2);
+                if constexpr (BLK == 3) scl *= expf(-p.soft * k2);
                 v[b * 8 + r].x *= scl; v[b * 8 + r].y *= scl;
             }
         if constexpr (R1 != 8) {
@@ -317,6 +319,8 @@ hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
 // dir < 0 forward, > 0 inverse, 0: forward, Green multiply, inverse
 hipError_t launch_col_any(pm_ctx *c, int dir, const col_pass &p, int blocks)
 {
+    if (dir == 0 && p.soft != 0.0f)
+        return c->g.G == 512 ? launch_col<512, -1, true, 3>(c, p, blocks) : launch_col<1024, -1, true, 3>(c, p, blocks);
     if (c->g.G == 512) {
         if (dir == 0) return launch_col<512, -1, true>(c, p, blocks);
         return dir < 0 ? launch_col<512, -1, false>(c, p, blocks) : launch_col<512, 1, false>(c, p, blocks);
