@@ -107,7 +107,7 @@ def kernel_bytes(n, m, G=512):
 
 
 # kernels that make up each timed stage (substrings of the names rocprofv3 reports)
-STAGE_KERNELS = {"bin": ["rocprim", "k_reorder", "k_row_start", "k_cell_keys"],
+STAGE_KERNELS = {"bin": ["rocprim", "k_onesweep_pass", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start", "k_cell_keys"],
                  "deposit": ["k_deposit_rows", "k_deposit_units", "k_sum_units"],
                  "fft_fwd": ["k_row_r2c", "k_col_fft<512, -1, false>"], "green": ["k_col_fft<512, -1, true>", "k_green"],
                  "fft_inv": ["k_col_fft<512, 1, false>", "k_row_c2r"], "gradient": ["k_gradient"], "gather": ["k_gather"]}

@@ -41,6 +41,174 @@ hipError_t sort_pairs(void *tmp, size_t &bytes, const uint32_t *kin, uint32_t *k
     return rocprim::radix_sort_pairs<sort_config<RADIX>>(tmp, bytes, kin, kout, vin, vout, n, 0, bits, s);
 }
 
+// ---- the same sort, driven from here ----------------------------------------------------------------------------
+// rocprim::radix_sort_pairs clears its bookkeeping with seven small fill commands per sort (the digit counts, and per
+// pass the look-back states and the ticket counter that numbers the blocks), each a launch of its own between the
+// passes.  The driver below runs the library's own device code (histogram, scan, one-sweep pass: rocprim::detail) on a
+// workspace that gives every pass its own look-back states and ticket counter, all cleared by ONE fill before the
+// histogram kernel.  Same keys, same stable order.
+#ifndef PM_OWN_ONESWEEP
+#define PM_OWN_ONESWEEP 1
+#endif
+
+using ticket_t = rocprim::detail::block_id_wrapper<unsigned int, true>;     // blocks take their number from an atomic counter
+using lookback_t = rocprim::detail::onesweep_lookback_state;
+
+#ifndef PM_RUN_HIST
+#define PM_RUN_HIST 1
+#endif
+
+#if PM_RUN_HIST
+// Digit counts of every place in one pass over the keys.  The keys arrive in the cell order of the step before, so
+// neighbouring keys mostly agree in their upper digits and often in all of them: a thread takes 16 consecutive keys at a time
+// and adds one count per run of equal digits to the block's LDS table instead of one per key (the library's kernel,
+// one LDS add per key and place, spends most of its 43 us at 16.7 M keys on adds that collide on one counter).
+#ifndef PM_COUNT_BLOCK
+#define PM_COUNT_BLOCK 1024
+#endif
+#ifndef PM_COUNT_GRID
+#define PM_COUNT_GRID 512
+#endif
+constexpr unsigned COUNT_ITEMS = 16;
+template <unsigned RADIX>
+__global__ void __launch_bounds__(PM_COUNT_BLOCK)
+k_digit_counts(const uint32_t *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t size, uint32_t /*full_blocks*/, unsigned bits)
+{
+    constexpr unsigned ITEMS = COUNT_ITEMS, MAX_PLACES = (32 + RADIX - 1) / RADIX, SIZE = 1u << RADIX;
+    static_assert(ITEMS % 4 == 0, "keys are loaded four at a time");
+    __shared__ uint32_t table[MAX_PLACES * SIZE];
+    const unsigned places = (bits + RADIX - 1) / RADIX;
+    for (unsigned q = threadIdx.x; q < places * SIZE; q += PM_COUNT_BLOCK) table[q] = 0u;
+    __syncthreads();
+    // the blocks stride over the keys in chunks of PM_COUNT_BLOCK * ITEMS, so that a block's table is flushed once
+    const uint64_t stride = (uint64_t)gridDim.x * PM_COUNT_BLOCK * ITEMS;
+    for (uint64_t first = ((uint64_t)blockIdx.x * PM_COUNT_BLOCK + threadIdx.x) * ITEMS; first < size; first += stride) {
+        uint32_t k[ITEMS];
+        const unsigned have = size - first < ITEMS ? (unsigned)(size - first) : ITEMS;
+        if (have == ITEMS) {
+            const uint4 *src = (const uint4 *)(keys + first);
+#pragma unroll
+            for (unsigned q = 0; q < ITEMS / 4; ++q) {
+                const uint4 v = src[q];
+                k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (unsigned q = 0; q < ITEMS; ++q) k[q] = q < have ? keys[first + q] : 0u;
+        }
+        for (unsigned place = 0, bit = 0; place < places; ++place, bit += RADIX) {
+            const uint32_t mask = (bits - bit < RADIX ? (1u << (bits - bit)) : SIZE) - 1u;
+            uint32_t *row = table + place * SIZE;
+            uint32_t cur = (k[0] >> bit) & mask, run = 1;
+#pragma unroll
+            for (unsigned q = 1; q < ITEMS; ++q) {
+                const uint32_t d = (k[q] >> bit) & mask;
+                if (q < have) {
+                    if (d == cur) ++run;
+                    else { atomicAdd(row + cur, run); cur = d; run = 1; }
+                }
+            }
+            atomicAdd(row + cur, run);
+        }
+    }
+    __syncthreads();
+    for (unsigned q = threadIdx.x; q < places * SIZE; q += PM_COUNT_BLOCK) {
+        const uint32_t v = table[q];
+        if (v) atomicAdd(counts + q, v);
+    }
+}
+#else
+template <unsigned RADIX>
+__global__ void __launch_bounds__(PM_HIST_BLOCK)
+k_digit_counts(const uint32_t *keys, uint32_t *counts, uint32_t size, uint32_t full_blocks, unsigned bits)
+{
+    rocprim::detail::onesweep_histograms<PM_HIST_BLOCK, PM_HIST_ITEMS, RADIX, false>(keys, counts, size, full_blocks, rocprim::identity_decomposer{}, 0u, bits);
+}
+#endif
+
+template <unsigned RADIX>
+__global__ void __launch_bounds__(PM_HIST_BLOCK)
+k_digit_offsets(uint32_t *counts)
+{
+    rocprim::detail::onesweep_scan_histograms<PM_HIST_BLOCK, RADIX>(counts);
+}
+
+template <unsigned RADIX>
+__global__ void __launch_bounds__(PM_SORT_BLOCK)
+k_onesweep_pass(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t size, uint32_t *offsets_in, uint32_t *offsets_out,
+                lookback_t *lookback, unsigned bit, unsigned place_bits, uint32_t full_blocks, ticket_t ticket)
+{
+    rocprim::detail::onesweep_iteration<PM_SORT_BLOCK, PM_SORT_ITEMS, RADIX, false, rocprim::block_radix_rank_algorithm::match>(
+        kin, kout, vin, vout, size, offsets_in, offsets_out, lookback, rocprim::identity_decomposer{}, bit, place_bits, full_blocks, ticket);
+}
+
+constexpr size_t SORT_ALIGN = 256;
+inline size_t aligned(size_t b) { return (b + SORT_ALIGN - 1) / SORT_ALIGN * SORT_ALIGN; }
+
+// workspace: [tickets | look-back states of every pass | digit counts of every pass | spare offsets] (cleared per sort),
+// then the scratch keys and values
+struct sort_plan {
+    unsigned radix, places, blocks;
+    size_t tickets, lookback, counts, spare, cleared, keys_tmp, values_tmp, bytes;
+};
+
+template <unsigned RADIX>
+sort_plan plan_sort(size_t n, unsigned bits)
+{
+    sort_plan p{};
+    p.radix = 1u << RADIX;
+    p.places = (bits + RADIX - 1) / RADIX;
+    p.blocks = (unsigned)((n + (size_t)PM_SORT_BLOCK * PM_SORT_ITEMS - 1) / ((size_t)PM_SORT_BLOCK * PM_SORT_ITEMS));
+    p.tickets = 0;
+    p.lookback = aligned(p.places * sizeof(uint32_t));
+    p.counts = p.lookback + aligned((size_t)p.places * p.radix * p.blocks * sizeof(lookback_t));
+    p.spare = p.counts + aligned((size_t)p.places * p.radix * sizeof(uint32_t));
+    p.cleared = p.spare + aligned((size_t)p.radix * sizeof(uint32_t));
+    p.keys_tmp = p.cleared;
+    p.values_tmp = p.keys_tmp + aligned(n * sizeof(uint32_t));
+    p.bytes = p.values_tmp + aligned(n * sizeof(uint32_t));
+    return p;
+}
+
+template <unsigned RADIX>
+hipError_t own_sort_pairs(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
+                          hipStream_t s)
+{
+    const sort_plan p = plan_sort<RADIX>(n, bits);
+    if (p.bytes > tmp_bytes || n >= ((size_t)1 << 30)) return hipErrorOutOfMemory;       // one batch of the library's pass: below 2^30 pairs
+    char *w = (char *)tmp;
+    uint32_t *tickets = (uint32_t *)(w + p.tickets), *counts = (uint32_t *)(w + p.counts), *spare = (uint32_t *)(w + p.spare);
+    lookback_t *lookback = (lookback_t *)(w + p.lookback);
+    uint32_t *ktmp = (uint32_t *)(w + p.keys_tmp), *vtmp = (uint32_t *)(w + p.values_tmp);
+    hipError_t e = hipMemsetAsync(w, 0, p.cleared, s);
+    if (e != hipSuccess) return e;
+#if PM_RUN_HIST
+    const size_t per_count = (size_t)PM_COUNT_BLOCK * COUNT_ITEMS;
+    const size_t want = (n + per_count - 1) / per_count;
+    k_digit_counts<RADIX><<<(unsigned)(want < PM_COUNT_GRID ? want : PM_COUNT_GRID), PM_COUNT_BLOCK, 0, s>>>(kin, counts, (uint32_t)n, 0u, bits);
+#else
+    const size_t per_hist = (size_t)PM_HIST_BLOCK * PM_HIST_ITEMS;
+    const uint32_t hist_blocks = (uint32_t)((n + per_hist - 1) / per_hist), hist_full = (uint32_t)(n / per_hist);
+    k_digit_counts<RADIX><<<hist_blocks, PM_HIST_BLOCK, 0, s>>>(kin, counts, (uint32_t)n, hist_full, bits);
+#endif
+    k_digit_offsets<RADIX><<<p.places, PM_HIST_BLOCK, 0, s>>>(counts);
+    const size_t per_block = (size_t)PM_SORT_BLOCK * PM_SORT_ITEMS;
+    const uint32_t full_blocks = (uint32_t)(n / per_block);
+    // the last pass must end in the output: with an odd number of passes the first one goes there too
+    bool to_output = (p.places - 1) % 2 == 0, from_input = true;
+    for (unsigned place = 0, bit = 0; place < p.places; ++place, bit += RADIX) {
+        const uint32_t *ki = from_input ? kin : to_output ? ktmp : kout, *vi = from_input ? vin : to_output ? vtmp : vout;
+        uint32_t *ko = to_output ? kout : ktmp, *vo = to_output ? vout : vtmp;
+        const unsigned now = bits - bit < RADIX ? bits - bit : RADIX;
+        k_onesweep_pass<RADIX><<<p.blocks, PM_SORT_BLOCK, 0, s>>>(ki, ko, vi, vo, (uint32_t)n, counts + (size_t)place * p.radix, spare,
+                                                                  lookback + (size_t)place * p.radix * p.blocks, bit, now, full_blocks,
+                                                                  ticket_t::create(tickets + place));
+        from_input = false;
+        to_output = !to_output;
+    }
+    return hipGetLastError();
+}
+
 __global__ void k_iota(uint32_t *__restrict__ out, int64_t n)
 {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -68,6 +236,11 @@ size_t pm_sort_tmp_bytes(int64_t cap)
         size_t b = 0;
         with_radix(bits, [&](auto r) { return sort_pairs<decltype(r)::value>(nullptr, b, k, k, v, v, (size_t)cap, 32, (hipStream_t)0); });
         most = b > most ? b : most;
+        // the own driver: 32 key bits at most, in places of 8 or 9 bits
+        for (unsigned kb : {8u, 27u, 32u}) {
+            with_radix(kb, [&](auto r) { b = plan_sort<decltype(r)::value>((size_t)cap, kb).bytes; return hipSuccess; });
+            most = b > most ? b : most;
+        }
     }
     return most;
 }
@@ -81,6 +254,11 @@ hipError_t pm_sort_fill_iota(pm_ctx *c)
 hipError_t pm_sort_pairs(pm_ctx *c, int bits)
 {
     if (c->n == 0) return hipSuccess;
+#if PM_OWN_ONESWEEP
+    return with_radix((unsigned)bits, [&](auto r) {
+        return own_sort_pairs<decltype(r)::value>(c->sort_tmp, c->sort_tmp_bytes, c->key_in, c->key_out, c->iota, c->src, (size_t)c->n, (unsigned)bits, c->stream);
+    });
+#endif
     size_t need = 0;
     auto run = [&](void *tmp) {
         return with_radix((unsigned)bits, [&](auto r) {
