@@ -133,9 +133,11 @@ k_digit_offsets(uint32_t *counts)
     rocprim::detail::onesweep_scan_histograms<PM_HIST_BLOCK, RADIX>(counts);
 }
 
-template <unsigned RADIX>
+// VIn: where a pass reads its values -- the scratch or output array, or for the first pass a counting iterator (the
+// values that go in are the storage indices 0, 1, 2, ...: nothing to read)
+template <unsigned RADIX, class VIn>
 __global__ void __launch_bounds__(PM_SORT_BLOCK)
-k_onesweep_pass(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t size, uint32_t *offsets_in, uint32_t *offsets_out,
+k_onesweep_pass(const uint32_t *kin, uint32_t *kout, VIn vin, uint32_t *vout, uint32_t size, uint32_t *offsets_in, uint32_t *offsets_out,
                 lookback_t *lookback, unsigned bit, unsigned place_bits, uint32_t full_blocks, ticket_t ticket)
 {
     rocprim::detail::onesweep_iteration<PM_SORT_BLOCK, PM_SORT_ITEMS, RADIX, false, rocprim::block_radix_rank_algorithm::match>(
@@ -200,9 +202,16 @@ hipError_t own_sort_pairs(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint
         const uint32_t *ki = from_input ? kin : to_output ? ktmp : kout, *vi = from_input ? vin : to_output ? vtmp : vout;
         uint32_t *ko = to_output ? kout : ktmp, *vo = to_output ? vout : vtmp;
         const unsigned now = bits - bit < RADIX ? bits - bit : RADIX;
-        k_onesweep_pass<RADIX><<<p.blocks, PM_SORT_BLOCK, 0, s>>>(ki, ko, vi, vo, (uint32_t)n, counts + (size_t)place * p.radix, spare,
-                                                                  lookback + (size_t)place * p.radix * p.blocks, bit, now, full_blocks,
-                                                                  ticket_t::create(tickets + place));
+        uint32_t *offsets = counts + (size_t)place * p.radix;
+        lookback_t *states = lookback + (size_t)place * p.radix * p.blocks;
+        const ticket_t ticket = ticket_t::create(tickets + place);
+#ifndef PM_SORT_READ_IOTA
+        if (from_input && vin == nullptr)
+            k_onesweep_pass<RADIX><<<p.blocks, PM_SORT_BLOCK, 0, s>>>(ki, ko, rocprim::counting_iterator<uint32_t>(0), vo, (uint32_t)n, offsets, spare, states,
+                                                                      bit, now, full_blocks, ticket);
+        else
+#endif
+            k_onesweep_pass<RADIX><<<p.blocks, PM_SORT_BLOCK, 0, s>>>(ki, ko, vi, vo, (uint32_t)n, offsets, spare, states, bit, now, full_blocks, ticket);
         from_input = false;
         to_output = !to_output;
     }
@@ -256,7 +265,13 @@ hipError_t pm_sort_pairs(pm_ctx *c, int bits)
     if (c->n == 0) return hipSuccess;
 #if PM_OWN_ONESWEEP
     return with_radix((unsigned)bits, [&](auto r) {
-        return own_sort_pairs<decltype(r)::value>(c->sort_tmp, c->sort_tmp_bytes, c->key_in, c->key_out, c->iota, c->src, (size_t)c->n, (unsigned)bits, c->stream);
+        // values in: none (the storage indices are counted, not read); PM_SORT_READ_IOTA reads them from the table instead
+#ifdef PM_SORT_READ_IOTA
+        const uint32_t *vin = c->iota;
+#else
+        const uint32_t *vin = nullptr;
+#endif
+        return own_sort_pairs<decltype(r)::value>(c->sort_tmp, c->sort_tmp_bytes, c->key_in, c->key_out, vin, c->src, (size_t)c->n, (unsigned)bits, c->stream);
     });
 #endif
     size_t need = 0;
