@@ -673,8 +673,14 @@ k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
 
 // One block per listed density row: what its own wave summed, then the units of its crowded sources
 // (q = 0..3, units in order; a thread per column, four loads in flight), then emitted like any other row.
+// threads per block of k_sum_units: a column each at G = 512
+#ifndef PM_SUM_BLOCK
+#define PM_SUM_BLOCK 512
+#endif
+constexpr int SUM_BLOCK = PM_SUM_BLOCK;
+
 template <int NFFT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(SUM_BLOCK)
 k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, const uint2 *__restrict__ heavy_rows,
             const uint32_t *__restrict__ counters, const double *__restrict__ unit_rows, const double *__restrict__ light_rows,
             float *__restrict__ density, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle, pm_geom g,
@@ -684,7 +690,7 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_un
     const int G = g.G;
     float2 *tw = (float2 *)(lds_rows + G);
     if constexpr (NFFT != 0) {
-        for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
+        for (int q = threadIdx.x; q < NFFT; q += SUM_BLOCK) tw[q] = twiddle[q];
     }
     // housekeeping of the last kernel of a deposit: the next deposit's counters (the other set: nobody uses it now)
     // start at zero, and the host learns how many units this one had (a word of page-locked host memory)
@@ -696,7 +702,7 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_un
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
         const uint2 entry = heavy_rows[e];
         const row_runs t = runs_of(rs, row_unit, entry.x, g);
-        for (int c = threadIdx.x; c < G; c += BLOCK) {
+        for (int c = threadIdx.x; c < G; c += SUM_BLOCK) {
             double sum = entry.y ? light_rows[(size_t)e * G + c] : 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -705,6 +711,23 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_un
                 const size_t step = (size_t)4 * G;
                 const double *in = unit_rows + ((size_t)t.unit[q] * 4 + q) * G + c;
                 uint32_t u = 0;
+#ifndef PM_SUM_NO16
+                for (; u + 16 <= units; u += 16, in += 16 * step) {
+                    double v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = in[k * step];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sum += v[k];
+                }
+#endif
+#ifndef PM_SUM_NO8
+                // sixteen / eight loads in flight for the long runs of units (the adds keep their order)
+                for (; u + 8 <= units; u += 8, in += 8 * step) {
+                    const double v0 = in[0], v1 = in[step], v2 = in[2 * step], v3 = in[3 * step];
+                    const double v4 = in[4 * step], v5 = in[5 * step], v6 = in[6 * step], v7 = in[7 * step];
+                    sum += v0; sum += v1; sum += v2; sum += v3; sum += v4; sum += v5; sum += v6; sum += v7;
+                }
+#endif
                 for (; u + 4 <= units; u += 4, in += 4 * step) {
                     const double v0 = in[0], v1 = in[step], v2 = in[2 * step], v3 = in[3 * step];
                     sum += v0; sum += v1; sum += v2; sum += v3;
@@ -1040,7 +1063,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
         c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g);
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
-    k_sum_units<NFFT><<<2048, BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
+    k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
                                                                                         c->light_rows, c->density, c->spectrum, c->twiddle, c->g,
                                                                                         next_counters, c->units_seen_dev);
     return hipGetLastError();
