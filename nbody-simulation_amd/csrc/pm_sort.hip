@@ -264,7 +264,8 @@ hipError_t pm_sort_pairs(pm_ctx *c, int bits)
 {
     if (c->n == 0) return hipSuccess;
 #if PM_OWN_ONESWEEP
-    return with_radix((unsigned)bits, [&](auto r) {
+    // (2^30 pairs and more go through the library's call below, which cuts its passes into batches)
+    if (c->n < ((int64_t)1 << 30)) return with_radix((unsigned)bits, [&](auto r) {
         // values in: none (the storage indices are counted, not read); PM_SORT_READ_IOTA reads them from the table instead
 #ifdef PM_SORT_READ_IOTA
         const uint32_t *vin = c->iota;
