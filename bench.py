@@ -106,6 +106,17 @@ def kernel_bytes(n, m, G=512):
             "gather": ("k_gather", 48 * n + 4 * m)}
 
 
+def fused_stage_bytes(n, m):
+    """What each timed stage of the fused pipeline (G = 512 / 1024) cannot avoid moving: the deposit reads the 16-byte
+    fraction records and writes the half spectrum (4M) already transformed along z; each column pass reads and writes
+    the half spectrum once (8M; the pass along x does so once for forward, Green multiply and inverse together);
+    `fft_inv` is the inverse pass along y plus the inverse row transform (4M in, 4M out); the gather reads and writes
+    position and velocity records (48N) and reads the potential once (4M).  These are smaller than the per-stage shares
+    of 64N + 80M, which count every mesh the staged pipeline materialises."""
+    return {"bin": 0, "deposit": 16 * n + 4 * m, "fft_fwd": 8 * m, "green": 8 * m, "fft_inv": 16 * m, "gradient": 0,
+            "gather": 48 * n + 4 * m}
+
+
 # kernels that make up each timed stage (substrings of the names rocprofv3 reports)
 STAGE_KERNELS = {"bin": ["rocprim", "k_onesweep_pass", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start", "k_cell_keys"],
                  "deposit": ["k_deposit_rows", "k_deposit_units", "k_sum_units"],
@@ -256,6 +267,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         custom = fused and G in (512, 1024)         # the grid sizes of the hand-written transforms: fused pipeline
         b = stage_bytes(n, m, custom)
+        sb = fused_stage_bytes(n, m) if custom else b
         per = {s: (ms / c if c else 0.0) for s, (ms, c) in stages.items()}
         if custom:
             # the dominant kernel: the longest-running stage that is a single launch, priced with what it must move
@@ -282,9 +294,9 @@ def main():
             "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved": b_step / (ms_step * 1e-3) / 1e9,
                               "unit": "GB/s", "frac": b_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "stage_ms": per,
-            # every timed stage against the same peak, with the stage's share of the step's algorithmic bytes
-            "stage_roofline": {st: {"algorithmic_bytes": b[st], "achieved": b[st] / (per[st] * 1e-3) / 1e9, "unit": "GB/s",
-                                    "frac": b[st] / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for st in per if b[st] > 0 and per[st] > 0},
+            # every timed stage against the same peak, with the bytes the stage cannot avoid in the pipeline that ran
+            "stage_roofline": {st: {"bytes": sb[st], "achieved": sb[st] / (per[st] * 1e-3) / 1e9, "unit": "GB/s",
+                                    "frac": sb[st] / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for st in per if sb[st] > 0 and per[st] > 0},
         }
         if args.cpu_baseline == "auto" and world == 1:
             out["cpu_baseline"] = cpu_baseline(pos, vel, mass, G, L, DT)
