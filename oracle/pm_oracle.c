@@ -6,7 +6,7 @@
  * bench.py may load this; the product path never does.
  *
  * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
- * here bit for bit against tests/golden/*.npz, which were written by running
+ * here bit for bit against the .npz files under tests/golden, which were written by running
  * the reference's own functions (tools/make_golden.py).
  *
  * Arithmetic contract (what numba compiles the reference loops to):
