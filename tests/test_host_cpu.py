@@ -70,6 +70,12 @@ def test_bench_workloads():
     b = bench.stage_bytes(100, 1000)
     assert sum(b.values()) == 64 * 100 + 80 * 1000
     assert sum(bench.stage_bytes(100, 1000, fused=True).values()) == 64 * 100 + 80 * 1000
+    # what the fused stages cannot avoid is less than their share of 64 N + 80 M, stage by stage, and the single-launch
+    # stages are priced the same way in both tables
+    f, share = bench.fused_stage_bytes(100, 1000), bench.stage_bytes(100, 1000, fused=True)
+    assert all(f[s] <= share[s] for s in f) and sum(f.values()) == 64 * 100 + 40 * 1000
+    k = bench.kernel_bytes(100, 1000)
+    assert all(k[s][1] == f[s] for s in k)
 
 
 def test_import_galaxy_matches_golden(golden):
