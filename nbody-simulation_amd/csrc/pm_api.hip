@@ -102,6 +102,8 @@ int ensure_binned(pm_ctx *c)
     HIP_TRY(c, pm_launch_reorder(c));
     HIP_TRY(c, pm_launch_row_start(c));
     c->binned = true;
+    // forces / forces64 are indexed by the storage slots of before the reorder: no longer attached to their particles
+    c->have_forces = false; c->have_forces64 = false;
     return PM_OK;
 }
 

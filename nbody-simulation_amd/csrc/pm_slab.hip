@@ -116,6 +116,7 @@ int ensure_binned(pm_ctx *c)
     c->n -= c->leaving;         // they carry the last key: the tail of the cell order
     c->leaving = 0;
     c->binned = true;
+    c->have_forces = false; c->have_forces64 = false;      // indexed by the storage slots of before the reorder
     return PM_OK;
 }
 

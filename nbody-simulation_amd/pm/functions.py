@@ -12,13 +12,18 @@ loop run unchanged with every stage on the GPU:
 This granular mode copies every array over PCIe on every call; it exists for parity tests and
 plumbing.  The fast path is pm.Simulation, which keeps all state resident.
 """
+import time
+
 import numpy as np
 
 from . import _lib as L
 from .simulation import Simulation
 
-__all__ = ["CIC", "NGP", "compute_potential", "gradient", "force_CIC", "force_NGP", "kick_drift",
-           "compute_kinetic_energy", "compute_potential_energy", "import_galaxy", "release"]
+# `np` and `time` are part of what `from functions import *` hands to the reference's main.py (functions.py:1-2 import
+# them at module level and main.py:20, 33, 54, 60 use them through the star import), and so is elapsed_time
+# (functions.py:363-364, main.py:69, 86): they are exported here for the same reason.
+__all__ = ["np", "time", "CIC", "NGP", "compute_potential", "gradient", "force_CIC", "force_NGP", "kick_drift",
+           "compute_kinetic_energy", "compute_potential_energy", "import_galaxy", "elapsed_time", "release"]
 
 _engines = {}
 
@@ -176,3 +181,8 @@ def import_galaxy(path1, path2=None, separation=1.0, direction=(1, 0, 0), veloci
     va = va + np.asarray(-(total_b / (total_a + total_b)) * rel)
     vb = vb + np.asarray((total_a / (total_a + total_b)) * rel)
     return np.vstack((xa, xb)), np.vstack((va, vb)), np.concatenate((ma, mb)), np.concatenate((la, lb))
+
+
+def elapsed_time(start_time):
+    """Seconds since `start_time`, a time.time() stamp (functions.py:363-364)."""
+    return time.time() - start_time

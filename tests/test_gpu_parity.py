@@ -675,6 +675,90 @@ def test_main_shaped_driver_runs_both_ways():
             assert abs(u - v) <= 1e-5 * abs(v), (a, out)
 
 
+def test_shipped_grid_size_against_golden(pm, golden):
+    """G = 100, the grid size main.py:5 ships (not a power of two: rocFFT's plans, not the hand-written transforms),
+    one step on the shipped run's dtypes (float64 positions and velocities): cell indices bit for bit, density within
+    the deposit's bounds, potential 1e-5 max|phi|, the gather on the golden density's own field, x1 / v1, energies."""
+    base, g = golden("c1mini_g50.npz"), golden("c1mini_g100_step1.npz")
+    G, L, dt = int(g["G"]), int(base["L"]), float(base["dt"])
+    pos, vel, mass = base["pos0"], base["vel0"], base["mass"]
+    assert G == 100 and pos.dtype == np.float64 and vel.dtype == np.float64
+    c = g["s0_cell"].astype(np.int64)
+    ref_keys = (c[:, 0] * G + c[:, 1]) * G + c[:, 2]
+    order = O.sort_order(ref_keys)
+    for fused in (False, True):
+        with pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused) as sim:
+            keys, perm = sim.cell_keys()
+            assert np.array_equal(perm, order) and np.array_equal(keys, ref_keys[order])
+            if not fused:
+                sim.deposit()
+                assert_density(sim.density(), g["s0_density"], O.CIC_f64(pos, G, L, mass))
+                sim.set_mesh(0, g["s0_density"])                # the solve and the gather on the reference's own density
+                sim.solve_potential()
+                phi = sim.potential()
+                assert np.abs(phi[::7, ::7, ::7] - g["s0_potential_sample"]).max() <= 1e-5 * np.abs(g["s0_potential_sample"]).max()
+                sim.gradient()
+                sim.compute_forces()
+                f = sim.forces()
+                assert np.abs(f - g["s0_forces"]).max() <= 1e-4 * np.abs(g["s0_forces"]).max()
+                sim.set_particles(pos, vel, mass)
+            sim.step(dt)
+            x, v = sim.positions(), sim.velocities()
+            assert x.dtype == np.float32 and v.dtype == np.float64
+            dx = np.abs(x.astype(np.float64) - g["x1"])
+            assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+            assert np.abs(v - g["v1"]).max() <= 1e-5 * np.abs(g["v1"]).max()
+            ke, pe = sim.energies()
+            assert abs(ke - float(g["s0_KE"])) <= 1e-6 * abs(float(g["s0_KE"]))
+            assert abs(pe - float(g["s0_PE"])) <= 1e-4 * abs(float(g["s0_PE"]))
+
+
+def test_star_import_is_the_only_change_a_main_py_needs(monkeypatch):
+    """examples/main_star_import.py takes every name it uses from `from pm.functions import *`, as main.py:1 takes them
+    from the reference's module, and runs main.py:20-69 statement for statement.  Its state after three steps against
+    the oracle's loop on the same files."""
+    import os
+    import runpy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("STEPS", "3")
+    monkeypatch.setattr(sys, "argv", ["main_star_import.py"])
+    ns = runpy.run_path(os.path.join(root, "examples", "main_star_import.py"), run_name="__main__")
+    G, L, dt = ns["grid_size"], ns["box_size"], ns["dt"]
+    assert G == 100 and len(ns["trajectory"]) == 3 and len(ns["energies"]) == 1
+    x, v, m, lab = O.import_galaxy(*ns["galaxy_files"], separation=400.0, direction=(0.67, 0.33, 0), velocity=(-3000, 300, 0))
+    x += 0.5 * np.asarray(L, dtype=float) - x.mean(axis=0)
+    for _ in range(3):
+        x, v = O.pm_step(x, v, m, G, L, dt)
+    assert ns["positions"].dtype == np.float32 and ns["velocities"].dtype == np.float64
+    dx = np.abs(ns["positions"].astype(np.float64) - x)
+    assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+    assert np.abs(ns["velocities"] - v).max() <= 1e-5 * np.abs(v).max()
+
+
+def test_forces_do_not_survive_a_reorder(pm, golden):
+    """pm_forces on a set that is not in cell order yet, then a call that bins it (pm_get_cell_keys, pm_deposit): the
+    stored forces belong to the storage slots of before the reorder, so pm_get_forces must refuse rather than hand
+    them out against the wrong particles; computed again after the reorder they are the direct result."""
+    g = golden("uniform_n10000_g32.npz")
+    G, L = int(g["G"]), int(g["L"])
+    with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"]) as sim:
+        for w, a in zip((2, 3, 4), (g["s0_gx"], g["s0_gy"], g["s0_gz"])):
+            sim.set_mesh(w, a)
+        sim.compute_forces()
+        assert np.array_equal(sim.forces(), g["s0_forces"])
+        sim.cell_keys()                                     # bins: the storage order changes
+        with pytest.raises(pm.PMError):
+            sim.forces()
+        sim.compute_forces()
+        assert np.array_equal(sim.forces(), g["s0_forces"])
+        sim.set_particles(g["pos0"], g["vel0"], g["mass"])
+        sim.compute_forces()
+        sim.deposit()
+        with pytest.raises(pm.PMError):
+            sim.forces()
+
+
 def test_errors(pm):
     lib = pm.load()
     assert not lib.pm_create(1, 1.0, 10, 0, 0)

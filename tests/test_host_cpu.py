@@ -94,8 +94,52 @@ def test_import_galaxy_matches_golden(golden):
     assert len(one) == 3 and np.array_equal(one[0], g["single_pos"]) and np.array_equal(one[1], g["single_vel"])
 
 
+def test_star_import_supplies_what_main_py_takes_from_it():
+    """main.py:1 is `from functions import *` and the script then uses, without importing them itself, `time`
+    (main.py:20), `np` (:33, :54, :60), import_galaxy (:25), CIC / NGP / force_CIC / force_NGP (:40-41),
+    compute_potential (:51), the energy functions (:65-66) and elapsed_time (:69)."""
+    from pm import functions as F
+    ns = {}
+    exec("from pm.functions import *", ns)
+    for name in ("time", "np", "import_galaxy", "CIC", "NGP", "force_CIC", "force_NGP", "compute_potential",
+                 "compute_kinetic_energy", "compute_potential_energy", "elapsed_time"):
+        assert name in F.__all__ and name in ns, name
+    assert ns["np"] is np and ns["time"].time() > 0 and 0 <= ns["elapsed_time"](ns["time"].time()) < 1
+
+
+def test_every_free_name_of_the_reference_main_loop_is_exported():
+    """Where the reference is at hand (this container, not the GPU box): parse its main.py, lines 1-67, and check that
+    every name the script reads but neither binds nor imports itself -- i.e. expects from the star import or the
+    builtins -- is exported by pm.functions."""
+    import ast
+    import builtins
+    path = "/root/reference/main.py"
+    if not os.path.exists(path):
+        pytest.skip("the reference is not on this machine")
+    from pm import functions as F
+    lines = open(path, encoding="utf-8").read().splitlines()[:67]
+    assert lines[0].strip() == "from functions import *"
+    tree = ast.parse("\n".join(lines[1:]))
+    bound, read = set(), set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Name):
+            (bound if isinstance(node.ctx, ast.Store) else read).add(node.id)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            bound.update((a.asname or a.name).split(".")[0] for a in node.names)
+    free = {n for n in read - bound if not hasattr(builtins, n)}
+    assert free and free <= set(F.__all__), free - set(F.__all__)
+
+
 def test_galaxy_classes():
     from pm.galaxy_classes import DiskGalaxy, Galaxy, generate_galaxy
+    # positional order of galaxy_classes.py:26-35: (morphology, sampling, N_particles, Rd, z0, M_tot, seed)
+    d = DiskGalaxy("disk", "importance", 100, 10, 1)
+    assert d.Rd == 10 and d.z0 == 1 and d.M_tot == 100 and d.seed is None
+    d = DiskGalaxy("disk", "importance", 100, 10, 1, 2.5, 7)
+    assert (d.Rd, d.z0, d.M_tot, d.seed) == (10, 1, 2.5, 7) and str(d) == "disk_importance_7"
+    # galaxy_classes.py:6-13: (morphology, sampling, N_particles, M_tot, seed)
+    b = Galaxy("disk", "equal-mass", 50, 3.0, 9)
+    assert (b.N_particles, b.M_tot, b.seed) == (50, 3.0, 9) and Galaxy("disk", "equal-mass", 50).M_tot == 50
     gal = generate_galaxy("disk", "equal-mass", 10000, 10, 1, seed=42)
     assert isinstance(gal, DiskGalaxy) and isinstance(gal, Galaxy)
     assert str(gal) == "disk_equal-mass_42" and gal.M_tot == 10000 and gal.Rd == 10 and gal.z0 == 1
