@@ -143,6 +143,22 @@ int pm_get_cell_keys(pm_ctx *ctx, int64_t *keys, int64_t *perm);
  * drift, potential from before it, as the reference does).  Sums run in float64. */
 int pm_energies(pm_ctx *ctx, double *ke, double *pe);
 
+/* pm_energies for callers that cannot allocate or wait: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  It has no counterpart in the reference.  Same kernels and the same bits as pm_energies, but
+ *  - the partial sums of the two reductions live in a file-scope array in device memory (16 KiB per GPU, held until
+ *    the process ends) instead of a buffer the context allocated;
+ *  - the results go to two doubles in DEVICE memory, device_ke_pe[0] = KE and device_ke_pe[1] = PE, written by the
+ *    last kernels on the context's stream: the call returns without waiting and copies nothing to the host;
+ *  - it calls no hipMalloc, hipFree or other allocating routine (the array's device address was looked up by
+ *    pm_create).
+ * At most PM_NOALLOC_MAX_PARTICLES particles (PM_EINVAL beyond; pm_energies has no such limit): the array holds 1024
+ * partial sums per energy, one per block of 256 threads, so that each thread adds at most 1024 terms in sequence.
+ * Every call on a GPU uses that GPU's one array, which keeps the last call's contents; each call overwrites every
+ * entry it reads, so nothing needs clearing, but two calls that overlap on one GPU (two contexts on different
+ * streams) race: order them. */
+#define PM_NOALLOC_MAX_PARTICLES ((int64_t)1 << 28)
+int pm_energies_noalloc(pm_ctx *ctx, double *device_ke_pe);
+
 /* The nearest-grid-point branch (CIC_interpolation = False, main.py:9,40-41):
  * NGP(positions, grid_size, box_size, masses): functions.py:11-16 -- float64 mesh, read with
  * pm_get_mesh_f64(PM_MESH_DENSITY).  Returns PM_ERANGE where the reference raises IndexError (a

@@ -129,6 +129,7 @@ static int create_impl(pm_ctx *c)
     const size_t M = (size_t)c->g.M, cap = (size_t)c->cap;
     const size_t plane = (size_t)G * G, planes = (size_t)c->g.Gs;    // a slab context holds its own planes only
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, pm_noalloc_prepare(c->device));     // set-up for pm_energies_noalloc, which may not do it under a capture
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

@@ -4,10 +4,17 @@
 // exactly like NumPy evaluates them in the positions' dtype.
 #include "pm_internal.hpp"
 
+#include <mutex>
+
 namespace {
 
 constexpr int BLOCK = 256;
 constexpr int RED_BLOCKS = 1024;
+
+// Scratch of pm_energies_noalloc: the per-block partial sums of the two reductions (kinetic, potential), 16 KiB that
+// every GPU the library runs on holds until the process ends.  In host code the array's name only stands for the
+// symbol; the address the device uses comes from hipGetSymbolAddress, once per device (noalloc_scratch below).
+static __device__ __align__(256) double scratch[2 * RED_BLOCKS];
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
@@ -265,11 +272,48 @@ k_ngp_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ P
 
 }  // namespace
 
+// Device address of `scratch` on `device`, looked up on first use with that device current; every GPU has its own
+// copy of the array at its own address.
+static hipError_t noalloc_scratch(int device, double **out)
+{
+    constexpr int MAX_DEVICES = 64;
+    static std::mutex lock;
+    static double *address[MAX_DEVICES] = {};
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(lock);
+    if (!address[device]) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return e;
+        double *p = nullptr;
+        e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        address[device] = p;
+    }
+    *out = address[device];
+    return hipSuccess;
+}
+
+hipError_t pm_noalloc_prepare(int device)
+{
+    double *p = nullptr;
+    return noalloc_scratch(device, &p);
+}
+
+static hipError_t launch_energies(pm_ctx *c, double *partials, double *d_ke, double *d_pe);
+
 // ke and pe are two doubles in device memory (c->diag + 2*RED_BLOCKS ...); the caller copies them out.
 hipError_t pm_launch_energies(pm_ctx *c, double *d_ke, double *d_pe)
 {
+    return launch_energies(c, c->diag, d_ke, d_pe);
+}
+
+// partials: 2 * RED_BLOCKS doubles.  Every launched block writes its own entry and k_reduce_final reads exactly the
+// entries of the launched blocks, so nothing in `partials` has to start at zero.
+static hipError_t launch_energies(pm_ctx *c, double *partials, double *d_ke, double *d_pe)
+{
     const int64_t n = c->n;
-    double *part_k = c->diag, *part_p = c->diag + RED_BLOCKS;
+    double *part_k = partials, *part_p = partials + RED_BLOCKS;
     int blocks = (int)((n + BLOCK - 1) / BLOCK);
     if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
     if (blocks < 1) blocks = 1;
@@ -350,4 +394,25 @@ hipError_t pm_launch_ngp_gather(pm_ctx *c, double dt, bool integrate, double *fo
         else k_ngp_gather<float, float><<<grid, BLOCK, 0, c->stream>>>(c->pf[u], c->pf[u], c->vf[v], gx, gy, gz, forces, c->n, c->g, dt, integrate);
     }
     return hipGetLastError();
+}
+
+// ---- the energies without any allocation --------------------------------------------------------------
+
+extern "C" int pm_energies_noalloc(pm_ctx *c, double *device_ke_pe)
+{
+    if (!c) return PM_EINVAL;
+    auto fail = [&](int code, const char *msg) { c->err = msg; return code; };
+    if (c->slab) return fail(PM_ESTATE, "pm_energies_noalloc works on the whole mesh: not on a slab context");
+    if (!c->pf[0]) return fail(PM_ESTATE, "no particles: call pm_set_particles first");
+    if (!device_ke_pe) return fail(PM_EINVAL, "device_ke_pe is NULL");
+    if (c->n > PM_NOALLOC_MAX_PARTICLES)
+        return fail(PM_EINVAL, "pm_energies_noalloc takes at most PM_NOALLOC_MAX_PARTICLES (268435456) particles: use pm_energies");
+    if ((c->flags & PM_FLAG_NGP) && !c->potential64)
+        return fail(PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
+    hipError_t e = hipSetDevice(c->device);
+    double *partials = nullptr;
+    if (e == hipSuccess) e = noalloc_scratch(c->device, &partials);
+    if (e == hipSuccess) e = launch_energies(c, partials, device_ke_pe, device_ke_pe + 1);
+    if (e != hipSuccess) { c->err = std::string("pm_energies_noalloc: ") + hipGetErrorString(e); return PM_EHIP; }
+    return PM_OK;
 }

@@ -201,6 +201,7 @@ hipError_t pm_launch_export_forces(pm_ctx *c, float *aos);
 hipError_t pm_launch_export_forces64(pm_ctx *c, double *aos);
 hipError_t pm_launch_export_keys(pm_ctx *c, int64_t *keys, int64_t *perm);
 hipError_t pm_launch_energies(pm_ctx *c, double *d_ke, double *d_pe);
+hipError_t pm_noalloc_prepare(int device);    // looks up the device address of pm_energies_noalloc's static scratch
 hipError_t pm_launch_force_ngp(pm_ctx *c);
 hipError_t pm_launch_ngp_keys(pm_ctx *c, uint32_t *bad);
 hipError_t pm_launch_ngp_sum(pm_ctx *c);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "pm_set_mesh": (_int, [_c_p, _int, _c_p]),
     "pm_get_cell_keys": (_int, [_c_p, _c_p, _c_p]),
     "pm_energies": (_int, [_c_p, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
+    "pm_energies_noalloc": (_int, [_c_p, _c_p]),
     "pm_deposit_ngp": (_int, [_c_p]),
     "pm_forces_ngp": (_int, [_c_p]),
     "pm_get_mesh_f64": (_int, [_c_p, _int, _c_p]),

@@ -147,6 +147,11 @@ class Simulation:
         self._ck(self.lib.pm_energies(self.ctx, ke, pe))
         return ke.value, pe.value
 
+    def energies_noalloc(self, device_address):
+        """pm_energies_noalloc: KE and PE into two float64 at `device_address` (DEVICE memory), queued on the
+        engine's stream: no allocation, no copy, no wait -- synchronize() before the result is read."""
+        self._ck(self.lib.pm_energies_noalloc(self.ctx, int(device_address)))
+
     def deposit_ngp(self):
         self._ck(self.lib.pm_deposit_ngp(self.ctx))
 
