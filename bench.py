@@ -6,7 +6,9 @@
 A "step" is one pass of deposit -> Poisson solve -> gradient -> gather + kick + drift over the
 whole particle set, with all state resident in HBM before the timed region starts.  At N=1 the
 workload is the headline configuration: a two-galaxy collision of 16,777,216 particles on a
-512^3 mesh.  Prints ONE JSON line (rank 0).
+512^3 mesh.  With --gpus N > 1 the same workload runs as ONE simulation over N slabs of the mesh
+(strong scaling; one process per GPU, exchanges over RCCL), started either by torch.distributed.run
+or, without a launcher, by this script itself.  Prints ONE JSON line (rank 0).
 
 The metric is particle-updates per second.  `roofline` prices the dominant stage against the
 8 TB/s HBM peak using the algorithmic bytes of that stage (one read and one write of each
@@ -97,13 +99,20 @@ def stage_bytes(n, m, fused=False):
             "gradient": 16 * m, "gather": 48 * n + 12 * m}
 
 
-def kernel_bytes(n, m, G=512):
-    """Stages of the fused pipeline that are ONE kernel launch, with the bytes that launch cannot avoid moving: a
-    column pass reads and writes the half spectrum once (8M, also when it transforms forward and back in one go), the
-    gather reads and writes position and velocity (48N) and reads the potential once (4M; the three gradient meshes
-    of the staged pipeline, 12M there, do not exist here)."""
-    return {"fft_fwd": (f"k_col_fft<{G}, -1, false>", 8 * m), "green": (f"k_col_fft<{G}, -1, true>", 8 * m),
-            "gather": ("k_gather", 48 * n + 4 * m)}
+def kernel_bytes(n, m, fused=True):
+    """Single kernel launches that pm_kernel_times reports, with the name rocprofv3 gives the kernel and the bytes one
+    launch cannot avoid moving.  The row kernel of the deposit is priced with the whole deposit's figure (it reads the
+    16-byte fraction records and writes the 4M bytes of the z-transformed density; the kernels beside and behind it
+    -- crowded rows in units, their sum -- share the same records and have no bytes of their own in this table); a
+    column pass reads and writes the half spectrum once (8M, also when it transforms forward and back in one go); the
+    inverse row transform reads the half spectrum and writes the potential (4M + 4M); the gather reads and writes
+    position and velocity (48N) and reads the potential once (4M; in the staged pipeline the three gradient meshes,
+    12M).  The sort passes and the reorder have no algorithmic bytes (cell order is not part of 64N + 80M): they are
+    reported with their durations only and cannot be the roofline kernel."""
+    return {"deposit_rows": ("k_deposit_rows", 16 * n + 4 * m), "col_y_fwd": ("k_col_fft<G, -1, false>", 8 * m),
+            "col_x_green": ("k_col_fft<G, -1, true>", 8 * m), "col_y_inv": ("k_col_fft<G, 1, false>", 8 * m),
+            "row_inv": ("k_row_c2r", 8 * m), "gather": ("k_gather", 48 * n + (4 * m if fused else 12 * m)),
+            "sort_pass": ("k_radix_pass", 0), "reorder": ("k_reorder", 0)}
 
 
 def fused_stage_bytes(n, m):
@@ -118,25 +127,28 @@ def fused_stage_bytes(n, m):
 
 
 # kernels that make up each timed stage (substrings of the names rocprofv3 reports)
-STAGE_KERNELS = {"bin": ["rocprim", "k_onesweep_pass", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start", "k_cell_keys"],
+STAGE_KERNELS = {"bin": ["k_radix_pass", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start", "k_cell_keys", "fillBuffer"],
                  "deposit": ["k_deposit_rows", "k_deposit_units", "k_sum_units"],
                  "fft_fwd": ["k_row_r2c", "k_col_fft<512, -1, false>"], "green": ["k_col_fft<512, -1, true>", "k_green"],
                  "fft_inv": ["k_col_fft<512, 1, false>", "k_row_c2r"], "gradient": ["k_gradient"], "gather": ["k_gather"]}
 
 
-def measured_traffic(stage):
-    """HBM bytes per step of a stage's kernels, from the committed rocprofv3 counter passes of this same
-    workload (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units,
-    FETCH_SIZE doubled for gfx950's half-counted wide reads).  None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+def measured_traffic(names, per_launch=False):
+    """HBM bytes of the kernels whose names contain one of `names`, from the newest committed rocprofv3 counter passes
+    of the headline workload (profiles/r*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB
+    units, FETCH_SIZE doubled for gfx950's half-counted wide reads): per step, or per launch of the kernel.  None if
+    there is no such file or kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
         return None
-    with open(path) as f:
+    with open(files[-1]) as f:
         per_kernel = json.load(f)["kernels"]
     total = 0.0
     for name, v in per_kernel.items():
-        if any(sub in name for sub in STAGE_KERNELS[stage]):
-            total += v["read_bytes_per_step"] + v["write_bytes_per_step"]
+        if any(sub in name for sub in names):
+            b = v["read_bytes_per_step"] + v["write_bytes_per_step"]
+            total += b / max(v.get("launches_per_step", 1), 1) if per_launch else b
     return total or None
 
 
@@ -157,7 +169,11 @@ def cpu_baseline(pos, vel, mass, G, L, dt):
             "host_cpus": os.cpu_count()}
 
 
-def main():
+def metric_name(args):
+    return f"particle-updates/sec per PM step (N={args.n}, {args.grid}^3 mesh); achieved HBM GB/s"
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -174,25 +190,74 @@ def main():
     ap.add_argument("--device-ic", action="store_true",
                     help="draw the workload on the GPU (pm_generate: same distributions, a counter-based random stream) "
                          "instead of building it with NumPy on the host; meant for the 64M+ particle configurations")
-    ap.add_argument("--no-slab-probe", action="store_true",
-                    help="--gpus N > 1 in replica mode: do not also run the slab-decomposed step in child processes")
-    ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
-                    help="--gpus N > 1: N independent replicas of the workload (default), or ONE run of the workload with the "
-                         "mesh cut into N slabs (all-to-all transposes, halo planes and particle migration over RCCL)")
+    ap.add_argument("--no-slab-probe", action="store_true", help="(no longer does anything; kept so that old command lines still parse)")
+    ap.add_argument("--repeats", type=int, default=4,
+                    help="single GPU: after the timed K steps, time this many more blocks of K steps and report every block "
+                         "(`ms_per_step_blocks`, `ms_per_step_median`); `value` stays the first block, as the contract says")
+    ap.add_argument("--parallelism", default=None, choices=["single", "slab", "replicas"],
+                    help="single: one context on one GPU (the default for --gpus 1).  slab: ONE run of the workload with the mesh cut "
+                         "into N slabs -- all-to-all transposes, halo planes and particle migration over RCCL (the default for "
+                         "--gpus N > 1; with --gpus 1 it runs the same code as one slab).  replicas: N independent copies of the "
+                         "single-GPU run, no collective")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="--parallelism slab (and the slab probe of a replica run): torch.distributed backend (gloo stages the exchanges through the host: for "
+                    help="--parallelism slab: torch.distributed backend (gloo stages the exchanges through the host: for "
                          "rehearsing the multi-rank run on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
+    if args.parallelism is None:
+        args.parallelism = "single" if args.gpus == 1 else "slab"
+    if args.parallelism == "single" and args.gpus != 1:
+        ap.error("--parallelism single is one GPU")
+    return args
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this one -- which has not
+    touched the GPU and does not -- with the environment torch.distributed.run would give them, pass rank 0's output
+    through, and return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                         stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    try:
+        pending = list(children)
+        while pending:
+            for ch in list(pending):
+                rc = ch.poll()
+                if rc is None:
+                    continue
+                pending.remove(ch)
+                worst = worst or rc
+                if rc != 0:                         # a rank died: the others would wait for it for ever
+                    for other in pending:
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for ch in children:
+            if ch.poll() is None:
+                ch.kill()
+    return worst
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         import torch                              # (counting devices does not touch the GPU)
         local_rank %= max(1, torch.cuda.device_count())       # more ranks than GPUs: rehearsals on a one-GPU box
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1")
 
     if args.parallelism == "slab":
         import torch                              # noqa: F401  (its HIP runtime has to be the one libpm.so binds to)
@@ -207,8 +272,7 @@ def main():
 
     n, G, L = args.n, args.grid, BOX
     m = G ** 3
-    # every rank holds an independent replica of the workload (its own seed); --parallelism slab runs ONE
-    # simulation over the ranks instead, and slab_probe() below reports that run beside this one
+    # replicas: every rank holds an independent copy of the workload (its own seed)
     fused = not args.no_fused_gradient
     if args.device_ic:
         sim = pm.Simulation(G, L, capacity=n, device=local_rank, fused_gradient=fused)
@@ -225,22 +289,28 @@ def main():
             dist.barrier()
         sim.synchronize()
 
+    def timed_block():
+        barrier()
+        t0 = time.perf_counter()
+        sim.step(DT, args.steps)
+        barrier()
+        return time.perf_counter() - t0
+
     sim.step(DT, args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    sim.step(DT, args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_block()
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+    # how steady the number is: the same block of K steps a few more times (the particles keep moving: not the same steps)
+    blocks = [elapsed / args.steps * 1e3] + [timed_block() / args.steps * 1e3 for _ in range(max(args.repeats, 0) if world == 1 else 0)]
 
-    # per-stage durations: HIP events on the engine's stream, same steps again
+    # per-stage and per-kernel durations: HIP events on the engine's stream around the launches, K more steps
     sim.set_flags(timing=True, fused_gradient=fused)
     sim.step(DT, args.steps)
     stages = sim.stage_times()
+    kernels = sim.kernel_times()
     sim.set_flags(timing=False, fused_gradient=fused)
 
     sim.close()
@@ -259,89 +329,60 @@ def main():
                 "ms_per_step": ue / args.steps * 1e3,
                 "step_roofline_frac": (64 * n + 80 * m) / (ue / args.steps) / 1e9 / HBM_PEAK_GBPS}
         del up, uv, um
-    slab = None
-    if world > 1 and not args.no_slab_probe:
-        slab = slab_probe(args, rank, world, dist)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        custom = fused and G in (512, 1024)         # the grid sizes of the hand-written transforms: fused pipeline
+        custom = fused and any(c for _, c in (kernels["col_x_green"],))     # the hand-written transforms ran: fused pipeline
         b = stage_bytes(n, m, custom)
         sb = fused_stage_bytes(n, m) if custom else b
         per = {s: (ms / c if c else 0.0) for s, (ms, c) in stages.items()}
-        if custom:
-            # the dominant kernel: the longest-running stage that is a single launch, priced with what it must move
-            kb = kernel_bytes(n, m, G)
-            dom = max(kb, key=lambda s: per[s])
-            dom_name, dom_bytes = kb[dom]
-        else:
-            dom = max((s for s in per if b[s] > 0), key=lambda s: per[s])
-            dom_name, dom_bytes = dom, b[dom]
-        ach = dom_bytes / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
-        b_step = 64 * n + 80 * m
+        kper = {k: (ms / c if c else 0.0) for k, (ms, c) in kernels.items()}
+        # the dominant kernel: the single launch that runs longest among those that have algorithmic bytes
+        kb = kernel_bytes(n, m, fused)
+        dom = max((k for k in kb if kb[k][1] > 0), key=lambda k: kper[k])
+        dom_name, dom_bytes = kb[dom][0].replace("<G,", f"<{G},"), kb[dom][1]
+        ach = dom_bytes / (kper[dom] * 1e-3) / 1e9 if kper[dom] > 0 else 0.0
+        headline = args.workload == "two_galaxy" and n == 16_777_216 and G == 512
+        b_step, b_pipe = 64 * n + 80 * m, 64 * n + (40 * m if custom else 80 * m)
+        bin_traffic = measured_traffic(STAGE_KERNELS["bin"]) if headline else None
         out = {
-            "metric": "particle-updates/sec per PM step (N=16M, 512^3 mesh)",
+            "metric": metric_name(args),
             "value": world * n * args.steps / elapsed, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (drawn on the device)" if args.device_ic else "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "fused_gradient": fused,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "stage": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(dom) if (args.workload == "two_galaxy" and n == 16_777_216 and G == 512) else None,
-                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": per[dom]},
+                         "traffic": measured_traffic([kb[dom][0].split("<")[0]], per_launch=True) if headline else None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": kper[dom],
+                         "launches_timed": kernels[dom][1]},
+            # the whole step against 64N + 80M (the staged pipeline's compulsory traffic, every mesh written and read once)
+            # and against what THIS pipeline cannot avoid (fused: no density mesh, no gradient meshes: 64N + 40M)
             "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved": b_step / (ms_step * 1e-3) / 1e9,
-                              "unit": "GB/s", "frac": b_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                              "unit": "GB/s", "frac": b_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "pipeline_bytes_per_step": b_pipe, "pipeline_frac": b_pipe / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "ms_per_step_blocks": [round(x, 4) for x in blocks], "ms_per_step_median": float(np.median(blocks)),
             "stage_ms": per,
-            # every timed stage against the same peak, with the bytes the stage cannot avoid in the pipeline that ran
+            "kernel_ms": {k: round(v, 5) for k, v in kper.items()},
+            # every timed stage against the same peak, with the bytes the stage cannot avoid in the pipeline that ran; the
+            # binning has none (cell order is not part of the algorithmic traffic): it is listed with what the counters saw
             "stage_roofline": {st: {"bytes": sb[st], "achieved": sb[st] / (per[st] * 1e-3) / 1e9, "unit": "GB/s",
                                     "frac": sb[st] / (per[st] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for st in per if sb[st] > 0 and per[st] > 0},
         }
+        if per["bin"] > 0:
+            out["stage_roofline"]["bin"] = {"bytes": 0, "measured_traffic": bin_traffic,
+                                            "achieved": (bin_traffic / (per["bin"] * 1e-3) / 1e9) if bin_traffic else None, "unit": "GB/s",
+                                            "frac": 0.0}
         if args.cpu_baseline == "auto" and world == 1:
             out["cpu_baseline"] = cpu_baseline(pos, vel, mass, G, L, DT)
         if also is not None:
             out["uniform_set"] = also
-        if slab is not None:
-            out["slab_decomposed"] = slab
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def slab_probe(args, rank, world, dist):
-    """The same workload as ONE simulation over `world` slabs (bench.py --parallelism slab), run by a child process
-    per rank with its own rendezvous, so that whatever happens to it -- RCCL has only ever run with one rank where this
-    was developed -- the replica measurement above stands.  Returns what rank 0's child printed, or what went wrong."""
-    import subprocess
-    env = dict(os.environ)
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 29)
-    # the children make a rendezvous of their own (rank 0's child hosts the store on that port).  The launcher's
-    # TORCHELASTIC_* variables would turn every child into a client of the launcher's store, which does not listen there.
-    for k in [k for k in env if k.startswith("TORCHELASTIC")]:
-        del env[k]
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(min(args.steps, 10)), "--warmup", "2",
-           "--parallelism", "slab", "--workload", args.workload, "--particles", str(args.n), "--grid", str(args.grid),
-           "--backend", args.backend]
-    dist.barrier()
-    if rank == 0:
-        print("bench: replica measurement done; probing the slab-decomposed step in child processes (at most 100 s)", file=sys.stderr, flush=True)
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode == 0 and (lines or rank != 0):
-            res = json.loads(lines[-1]) if lines else None
-            if res is not None:
-                res = {k: res[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "phases_ms")}
-        else:
-            res = {"error": f"exit code {r.returncode}: " + r.stderr[-400:]}
-    except subprocess.TimeoutExpired:
-        res = {"error": "no result within 100 s"}
-    except Exception as e:                           # the probe must not take the measurement down with it
-        res = {"error": repr(e)}
-    dist.barrier()
-    return res
 
 
 def slab_main(args, rank, world, local_rank):
@@ -394,11 +435,12 @@ def slab_main(args, rank, world, local_rank):
         b_step = 64 * n + 80 * G ** 3
         ach = b_step / (ms_step * 1e-3) / 1e9
         print(json.dumps({
-            "metric": "particle-updates/sec per PM step (N=16M, 512^3 mesh)", "value": n * args.steps / elapsed,
+            "metric": metric_name(args), "value": n * args.steps / elapsed,
             "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {G // world} planes",
-                       "particles_per_slab_at_start": loads, "backend": args.backend if world > 1 else None},
+                       "particles_per_slab_at_start": loads, "backend": args.backend if world > 1 else None,
+                       "collective_world_size": world},
             "phases_ms": phases,
             "roofline": {"bound": "hbm", "kernel": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None, "algorithmic_bytes_per_launch": b_step,

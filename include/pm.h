@@ -54,6 +54,13 @@ enum {
 enum { PM_STAGE_BIN = 0, PM_STAGE_DEPOSIT = 1, PM_STAGE_FFT_FWD = 2, PM_STAGE_GREEN = 3, PM_STAGE_FFT_INV = 4,
        PM_STAGE_GRADIENT = 5, PM_STAGE_GATHER = 6, PM_NSTAGES = 7 };
 
+/* single kernel launches reported by pm_kernel_times, in this order: a pass of the radix sort (one per digit place),
+ * the reorder into cell order, the deposit's row kernel, the column transforms along y (forward), along x (forward,
+ * Green multiply, inverse) and along y (inverse) and the inverse row transform of the hand-written Poisson solve,
+ * the gather (with kick, drift and the next cell keys) */
+enum { PM_KERNEL_SORT_PASS = 0, PM_KERNEL_REORDER = 1, PM_KERNEL_DEPOSIT_ROWS = 2, PM_KERNEL_COL_Y_FWD = 3, PM_KERNEL_COL_X_GREEN = 4,
+       PM_KERNEL_COL_Y_INV = 5, PM_KERNEL_ROW_INV = 6, PM_KERNEL_GATHER = 7, PM_NKERNELS = 8 };
+
 /* Replaces the module constants grid_size / box_size (main.py:5-6) and the
  * per-call allocations of every reference function.  n_capacity is the
  * largest particle count the context will hold.  Returns NULL on failure
@@ -235,6 +242,11 @@ int pm_slab_pitch(const pm_ctx *ctx);
 /* Accumulated milliseconds and call counts per stage since the last call
  * (needs PM_FLAG_TIMING); both arrays have PM_NSTAGES entries.  Synchronises. */
 int pm_stage_times(pm_ctx *ctx, float *ms, int *calls);
+/* The same for the single kernel launches listed under PM_KERNEL_*: accumulated milliseconds and launch counts since
+ * the last call (needs PM_FLAG_TIMING); both arrays have PM_NKERNELS entries.  ms[k] / calls[k] is the average duration
+ * of one launch, measured with HIP events on the stream the kernel is launched on.  The reference has no timers besides
+ * the wall clock of main.py:20, 69. */
+int pm_kernel_times(pm_ctx *ctx, float *ms, int *calls);
 
 /* Replace the flags given to pm_create (e.g. switch stage timing on for a profiling pass). */
 int pm_set_flags(pm_ctx *ctx, unsigned flags);

@@ -48,30 +48,18 @@ int dalloc(pm_ctx *c, T **p, size_t count)
 
 #define TRY(expr) do { int r_ = (expr); if (r_ != PM_OK) return r_; } while (0)
 
-struct stage_timer {
-    pm_ctx *c; int s; bool on;
-    stage_timer(pm_ctx *c_, int s_) : c(c_), s(s_), on((c_->flags & PM_FLAG_TIMING) != 0)
-    {
-        if (!on) return;
-        if (c->ev_used[s]) flush(c, s);
-        hipEventRecord(c->ev[s][0], c->stream);
-    }
-    ~stage_timer()
-    {
-        if (!on) return;
-        hipEventRecord(c->ev[s][1], c->stream);
-        c->ev_used[s] = true;
-    }
-    // One event pair per stage: the previous interval is read before the pair is reused.
-    static void flush(pm_ctx *c, int s)
-    {
-        if (!c->ev_used[s]) return;
-        float ms = 0.0f;
-        hipEventSynchronize(c->ev[s][1]);
-        if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) { c->ms[s] += ms; c->calls[s] += 1; }
-        c->ev_used[s] = false;
-    }
-};
+using stage_timer = pm_timer;
+struct kernel_timer : pm_timer { kernel_timer(pm_ctx *c, int k) : pm_timer(c, PM_NSTAGES + k) {} };
+
+// the event pairs of the stage and kernel timers, made when timing is first switched on
+int make_timing_events(pm_ctx *c)
+{
+    for (int s = 0; s < pm_ctx::TIMED; ++s)
+        for (int r = 0; r < pm_ctx::RING; ++r)
+            for (int k = 0; k < 2; ++k)
+                if (!c->ev[s][r][k]) HIP_TRY(c, hipEventCreate(&c->ev[s][r][k]));
+    return PM_OK;
+}
 
 int bits_for(int64_t M)
 {
@@ -137,16 +125,13 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipHostMalloc((void **)&c->units_seen, sizeof(uint32_t), hipHostMallocDefault));
     *c->units_seen = 1;
     HIP_TRY(c, hipHostGetDevicePointer((void **)&c->units_seen_dev, (void *)c->units_seen, 0));
-    for (int s = 0; s < PM_NSTAGES; ++s)
-        for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->ev[s][k]));
+    if (c->flags & PM_FLAG_TIMING) TRY(make_timing_events(c));
 
     // the deposit reads keys and fraction records in groups of four: three entries of slack
     TRY(dalloc(c, &c->frac, cap + 4));
     TRY(dalloc(c, &c->key_in, cap + 4));
     TRY(dalloc(c, &c->key_out, cap + 4));
     TRY(dalloc(c, &c->src, cap));
-    TRY(dalloc(c, &c->iota, cap));
-    HIP_TRY(c, pm_sort_fill_iota(c));
     c->sort_tmp_bytes = pm_sort_tmp_bytes(c->cap);
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, planes * G + 1));
@@ -242,7 +227,7 @@ void pm_destroy(pm_ctx *c)
     hipStreamSynchronize(c->stream);
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac);
-    hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->iota); hipFree(c->sort_tmp);
+    hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
     hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
@@ -259,9 +244,10 @@ void pm_destroy(pm_ctx *c)
     if (c->info) rocfft_execution_info_destroy(c->info);
     if (c->fwd) rocfft_plan_destroy(c->fwd);
     if (c->inv) rocfft_plan_destroy(c->inv);
-    for (int s = 0; s < PM_NSTAGES; ++s)
-        for (int k = 0; k < 2; ++k)
-            if (c->ev[s][k]) hipEventDestroy(c->ev[s][k]);
+    for (int s = 0; s < pm_ctx::TIMED; ++s)
+        for (int r = 0; r < pm_ctx::RING; ++r)
+            for (int k = 0; k < 2; ++k)
+                if (c->ev[s][r][k]) hipEventDestroy(c->ev[s][r][k]);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->units_seen) hipHostFree((void *)c->units_seen);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -286,7 +272,7 @@ int pm_set_stream(pm_ctx *c, void *hip_stream)
     if (!c) return PM_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int s = 0; s < PM_NSTAGES; ++s) stage_timer::flush(c, s);
+    for (int s = 0; s < pm_ctx::TIMED; ++s) pm_timer::flush(c, s);
     if (c->own_stream && c->stream) HIP_TRY(c, hipStreamDestroy(c->stream));
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
@@ -404,6 +390,7 @@ static int potential_impl(pm_ctx *c, bool have_z)
         stage_timer t(c, PM_STAGE_FFT_FWD);
         if (c->fft_custom) {
             if (!have_z) HIP_TRY(c, pm_launch_row_fft(c, true));
+            kernel_timer k(c, PM_KERNEL_COL_Y_FWD);
             HIP_TRY(c, pm_launch_col_fft(c, -1));
         } else {
             void *in[1] = {c->density}, *out[1] = {c->spectrum};
@@ -412,13 +399,19 @@ static int potential_impl(pm_ctx *c, bool have_z)
     }
     {
         stage_timer t(c, PM_STAGE_GREEN);
-        if (c->fft_custom) HIP_TRY(c, pm_launch_col_fft(c, 0));
-        else HIP_TRY(c, pm_launch_green(c));
+        if (c->fft_custom) {
+            kernel_timer k(c, PM_KERNEL_COL_X_GREEN);
+            HIP_TRY(c, pm_launch_col_fft(c, 0));
+        } else HIP_TRY(c, pm_launch_green(c));
     }
     {
         stage_timer t(c, PM_STAGE_FFT_INV);
         if (c->fft_custom) {
-            HIP_TRY(c, pm_launch_col_fft(c, 1));
+            {
+                kernel_timer k(c, PM_KERNEL_COL_Y_INV);
+                HIP_TRY(c, pm_launch_col_fft(c, 1));
+            }
+            kernel_timer k(c, PM_KERNEL_ROW_INV);
             HIP_TRY(c, pm_launch_row_fft(c, false));
         } else {
             void *in[1] = {c->spectrum}, *out[1] = {c->potential};
@@ -464,6 +457,7 @@ int pm_forces(pm_ctx *c)
 static int gather_kick_drift(pm_ctx *c, double dt, bool fused)
 {
     stage_timer t(c, PM_STAGE_GATHER);
+    kernel_timer k(c, PM_KERNEL_GATHER);
     HIP_TRY(c, pm_launch_gather(c, dt, true, false, fused));
     c->pos_f64 = false;      // positions are float32 from the first drift on (main.py:60)
     c->binned = false;
@@ -863,7 +857,8 @@ int pm_set_flags(pm_ctx *c, unsigned flags)
     flags |= c->flags & (PM_FLAG_ROCFFT_ONLY | PM_FLAG_NGP);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int s = 0; s < PM_NSTAGES; ++s) stage_timer::flush(c, s);
+    for (int s = 0; s < pm_ctx::TIMED; ++s) pm_timer::flush(c, s);
+    if (flags & PM_FLAG_TIMING) TRY(make_timing_events(c));
     c->flags = flags;
     return PM_OK;
 }
@@ -877,6 +872,21 @@ int pm_stage_times(pm_ctx *c, float *ms, int *calls)
         stage_timer::flush(c, s);
         if (ms) ms[s] = c->ms[s];
         if (calls) calls[s] = c->calls[s];
+        c->ms[s] = 0.0f; c->calls[s] = 0;
+    }
+    return PM_OK;
+}
+
+int pm_kernel_times(pm_ctx *c, float *ms, int *calls)
+{
+    if (!c) return PM_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < PM_NKERNELS; ++k) {
+        const int s = PM_NSTAGES + k;
+        pm_timer::flush(c, s);
+        if (ms) ms[k] = c->ms[s];
+        if (calls) calls[k] = c->calls[s];
         c->ms[s] = 0.0f; c->calls[s] = 0;
     }
     return PM_OK;

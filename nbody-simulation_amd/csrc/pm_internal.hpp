@@ -91,7 +91,6 @@ struct pm_ctx {
 
     // binning scratch
     uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;
-    uint32_t *iota = nullptr;           // 0, 1, 2, ...: the values the sort starts from (written once)
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
@@ -125,10 +124,13 @@ struct pm_ctx {
     float *forces = nullptr;            // (n,3) AoS in storage order
     void *stage = nullptr;              // staging for host copies: cap * 32 bytes
 
-    hipEvent_t ev[PM_NSTAGES][2] = {};
-    bool ev_used[PM_NSTAGES] = {};
-    float ms[PM_NSTAGES] = {};
-    int calls[PM_NSTAGES] = {};
+    // PM_FLAG_TIMING: per stage and per timed kernel (slots PM_NSTAGES ...) a ring of event pairs around the launches
+    static constexpr int TIMED = PM_NSTAGES + PM_NKERNELS, RING = 8;
+    hipEvent_t ev[TIMED][RING][2] = {};
+    int ev_head[TIMED] = {};            // ring entry the next interval uses
+    int ev_pending[TIMED] = {};         // intervals recorded and not read yet (the oldest is entry head - pending)
+    float ms[TIMED] = {};
+    int calls[TIMED] = {};
 
     // slab decomposition (pm_create_slab)
     bool slab = false;
@@ -149,6 +151,37 @@ struct pm_ctx {
     std::string err;
 };
 
+// Times what is enqueued on the context's stream during its lifetime into slot `s` (a PM_STAGE_* value, or PM_NSTAGES +
+// a PM_KERNEL_* value) when the context has PM_FLAG_TIMING.  An interval is read (the host waits for its end event) only
+// when its ring entry is needed again, RING intervals later, or by pm_timer::flush -- the host does not wait between
+// the launches of a step.
+struct pm_timer {
+    pm_ctx *c; int s; bool on;
+    pm_timer(pm_ctx *c_, int s_) : c(c_), s(s_), on((c_->flags & PM_FLAG_TIMING) != 0)
+    {
+        if (!on) return;
+        if (c->ev_pending[s] == pm_ctx::RING) read_oldest(c, s);
+        if (hipEventRecord(c->ev[s][c->ev_head[s]][0], c->stream) != hipSuccess) on = false;
+    }
+    ~pm_timer()
+    {
+        if (!on) return;
+        if (hipEventRecord(c->ev[s][c->ev_head[s]][1], c->stream) != hipSuccess) return;    // the interval is dropped
+        c->ev_head[s] = (c->ev_head[s] + 1) % pm_ctx::RING;
+        c->ev_pending[s] += 1;
+    }
+    static void read_oldest(pm_ctx *c, int s)
+    {
+        const int e = (c->ev_head[s] - c->ev_pending[s] + 2 * pm_ctx::RING) % pm_ctx::RING;
+        float ms = 0.0f;
+        if (hipEventSynchronize(c->ev[s][e][1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[s][e][0], c->ev[s][e][1]) == hipSuccess) {
+            c->ms[s] += ms; c->calls[s] += 1;
+        }
+        c->ev_pending[s] -= 1;
+    }
+    static void flush(pm_ctx *c, int s) { while (c->ev_pending[s] > 0) read_oldest(c, s); }
+};
+
 size_t pm_heavy_row_entries(int G, int64_t cap);
 size_t pm_max_units(int64_t cap);
 
@@ -162,10 +195,9 @@ hipError_t pm_launch_cell_keys(pm_ctx *c);
 // synthetic sets drawn on the device into the live float32 records; the number of parameters a kind takes (-1: no such kind)
 hipError_t pm_launch_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params);
 int pm_generate_param_count(int kind);
-hipError_t pm_sort_pairs(pm_ctx *c, int bits);
-hipError_t pm_sort_fill_iota(pm_ctx *c);      // c->iota[r] = r, once per context
-size_t pm_sort_tmp_bytes(int64_t cap);
+hipError_t pm_sort_pairs(pm_ctx *c, int bits);          // key_in -> key_out (sorted), src (storage slot of each sorted entry)
 hipError_t pm_launch_reorder(pm_ctx *c);
+size_t pm_sort_tmp_bytes(int64_t cap);
 hipError_t pm_settle_velocities(pm_ctx *c);     // must run before src is overwritten by a new sort
 hipError_t pm_launch_row_start(pm_ctx *c);
 hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum);

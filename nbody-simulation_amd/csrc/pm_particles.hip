@@ -7,6 +7,7 @@
 // -ffp-contract=off so no product is fused into an add.
 #include "pm_internal.hpp"
 #include "pm_fft_dev.hpp"
+#include "pm_cell_dev.hpp"
 
 namespace {
 
@@ -16,19 +17,6 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // index of the wave in its block, as a value the compiler knows to be the same in all lanes (so that
 // what is computed from it stays in scalar registers and is loaded through the scalar cache)
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-
-// Python-style x % L for L > 0 (functions.py:27-29): result in [0, L].
-__device__ __forceinline__ double wrap_f64(double x, double L)
-{
-    if (x >= 0.0 && x < L) return (x == 0.0) ? 0.0 : x;    // already inside: fmod is the identity
-    double r = fmod(x, L);
-    if (r != 0.0) {
-        if (r < 0.0) r += L;
-    } else {
-        r = 0.0;
-    }
-    return r;
-}
 
 // float32 np.remainder(x, L) for L > 0 (main.py:60): may return exactly L.
 __device__ __forceinline__ float wrap_f32(float x, float L)
@@ -43,41 +31,9 @@ __device__ __forceinline__ float wrap_f32(float x, float L)
     return r;
 }
 
-struct cell_t {
-    int i, j, k;
-    double dx, dy, dz;
-};
-
-// functions.py:27-43.  A scaled coordinate that rounds up to G (the reference would index out
-// of bounds there) is folded back to cell 0 of that axis.
-__device__ __forceinline__ cell_t locate(double px, double py, double pz, const pm_geom &g)
-{
-    cell_t c;
-    double sx = wrap_f64(px, g.L) * g.inv;
-    double sy = wrap_f64(py, g.L) * g.inv;
-    double sz = wrap_f64(pz, g.L) * g.inv;
-    c.i = (int)sx; c.j = (int)sy; c.k = (int)sz;
-    c.dx = sx - (double)c.i; c.dy = sy - (double)c.j; c.dz = sz - (double)c.k;
-    if (c.i >= g.G) c.i -= g.G;
-    if (c.j >= g.G) c.j -= g.G;
-    if (c.k >= g.G) c.k -= g.G;
-    return c;
-}
-
-template <typename TP>
-__device__ __forceinline__ cell_t locate(const pm_prec<TP> &p, const pm_geom &g)
-{
-    return locate((double)p.x, (double)p.y, (double)p.z, g);
-}
-
-// Sort key of a particle: its cell, counted from the first plane the context owns; one key past all
-// cells for a particle whose plane belongs to another slab.
-__device__ __forceinline__ uint32_t cell_key(const cell_t &c, const pm_geom &g)
-{
-    int il = c.i - g.i0;
-    if (g.Gs != g.G && (il < 0 || il >= g.Gs)) return (uint32_t)g.Gs * (uint32_t)g.G * (uint32_t)g.G;
-    return (uint32_t)(((int64_t)il * g.G + c.j) * g.G + c.k);
-}
+using pmcell::cell_t;
+using pmcell::locate;
+using pmcell::cell_key;
 
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
 
@@ -213,8 +169,7 @@ __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__re
     if (r >= n) return;
     const pm_prec<TP> rec = Pin[src[r]];
     Pout[r] = rec;
-    const cell_t c = locate(rec, g);
-    F[r] = pm_frac{(float)c.dx, (float)c.dy, (float)c.dz, rec.m};
+    F[r] = pmcell::fraction_record(rec, g);
 }
 
 // row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
@@ -1004,6 +959,7 @@ hipError_t pm_launch_reorder(pm_ctx *c)
     int64_t n = c->n;
     if (n == 0) return hipSuccess;
     int u = c->cur, w = 1 - u;
+    pm_timer timed(c, PM_NSTAGES + PM_KERNEL_REORDER);
     if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g);
     else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g);
     c->cur = w;
@@ -1060,8 +1016,11 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, counters,
                                                                   c->unit_rows, c->g);
     if (beside && (e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
-    k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
-        c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g);
+    {
+        pm_timer timed(c, PM_NSTAGES + PM_KERNEL_DEPOSIT_ROWS);
+        k_deposit_rows<NFFT><<<dim3((R + BLOCK / 64 - 1) / (BLOCK / 64)), BLOCK, lds_rows + tw_bytes, c->stream>>>(
+            c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g);
+    }
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
     k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
                                                                                         c->light_rows, c->density, c->spectrum, c->twiddle, c->g,

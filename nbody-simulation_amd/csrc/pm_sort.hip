@@ -1,68 +1,39 @@
-// Stable LSD radix sort of (cell key, storage index) pairs.  Stability is what makes the
-// cell order well defined: ties keep the current storage order.
+// Stable LSD radix sort of (cell key, storage index) pairs for gfx950, hand-written: one kernel counts the digits of
+// every place, one turns the counts into offsets, and every place takes ONE pass over the pairs ("one sweep": a
+// workgroup learns where its share of each digit goes from the workgroups before it through a chain of look-back
+// states instead of from a separate scan over per-workgroup histograms).  Stability is what makes the cell order well
+// defined: ties keep the current storage order (functions.py:27-39 defines the cells, the order of equal cells is the
+// order the particles are stored in).
+//
+// (Measured and not kept: a last pass that also fetches the position record of every pair and writes it, with its
+// fraction record, at the pair's place in cell order.  It saves reading the sorted indices again but holds a tile's
+// LDS and 86 registers per thread while the scattered reads are in flight: 303 us against 107 + 178 us for the pass
+// and the separate reorder kernel at 16.7 M particles.)
 #include "pm_internal.hpp"
 
-#include <cstring>
-#include <rocprim/rocprim.hpp>
-
-// block size and keys per thread of the histogram kernel that precedes the passes (16 keys per thread: 14 us less
-// than with 8 at 16.7 M keys; more is slower again)
-#ifndef PM_HIST_BLOCK
-#define PM_HIST_BLOCK 1024
-#endif
-#ifndef PM_HIST_ITEMS
-#define PM_HIST_ITEMS 16
-#endif
-#ifndef PM_SORT_BLOCK
-#define PM_SORT_BLOCK 1024
-#endif
-#ifndef PM_SORT_ITEMS
-#define PM_SORT_ITEMS 8
-#endif
+#include <atomic>
+#include <type_traits>
 
 namespace {
 
-// One pass over the pairs per "place" of RADIX bits.  The library's tuned default is 8 bits; with
-// 9 the 27 key bits of a 512^3 mesh take three passes instead of four.  1024 threads x 8 items of
-// 4 + 4 bytes fill the 64 KiB of LDS a block may use.
-template <unsigned RADIX>
-using sort_config = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<PM_HIST_BLOCK, PM_HIST_ITEMS>, rocprim::kernel_config<PM_SORT_BLOCK, PM_SORT_ITEMS>, RADIX,
-                                        rocprim::block_radix_rank_algorithm::match>>;
-
-// The values that go in are the storage indices 0, 1, 2, ...: read from a table that is written once, not made by a
-// counting iterator, because the library cannot tell that an iterator does not alias the output and then copies keys and
-// values into its scratch before the first pass (two more kernels, 32 us at 16.7 M pairs).
-template <unsigned RADIX>
-hipError_t sort_pairs(void *tmp, size_t &bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
-                      hipStream_t s)
-{
-    return rocprim::radix_sort_pairs<sort_config<RADIX>>(tmp, bytes, kin, kout, vin, vout, n, 0, bits, s);
-}
-
-// ---- the same sort, driven from here ----------------------------------------------------------------------------
-// rocprim::radix_sort_pairs clears its bookkeeping with seven small fill commands per sort (the digit counts, and per
-// pass the look-back states and the ticket counter that numbers the blocks), each a launch of its own between the
-// passes.  The driver below runs the library's own device code (histogram, scan, one-sweep pass: rocprim::detail) on a
-// workspace that gives every pass its own look-back states and ticket counter, all cleared by ONE fill before the
-// histogram kernel.  Same keys, same stable order.
-#ifndef PM_OWN_ONESWEEP
-#define PM_OWN_ONESWEEP 1
+constexpr int SORT_BLOCK = 1024;                    // threads of a pass's workgroup: 16 waves
+constexpr int SORT_WAVES = SORT_BLOCK / 64;
+#ifndef PM_SORT_ITEMS
+#define PM_SORT_ITEMS 8
 #endif
+constexpr int SORT_ITEMS = PM_SORT_ITEMS;           // pairs per thread
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // pairs per workgroup
 
-using ticket_t = rocprim::detail::block_id_wrapper<unsigned int, true>;     // blocks take their number from an atomic counter
-using lookback_t = rocprim::detail::onesweep_lookback_state;
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-#ifndef PM_RUN_HIST
-#define PM_RUN_HIST 1
-#endif
+template <typename K> __device__ __forceinline__ uint32_t digit_of(K key, unsigned bit, uint32_t mask) { return (uint32_t)(key >> bit) & mask; }
 
-#if PM_RUN_HIST
-// Digit counts of every place in one pass over the keys.  The keys arrive in the cell order of the step before, so
-// neighbouring keys mostly agree in their upper digits and often in all of them: a thread takes 16 consecutive keys at a time
-// and adds one count per run of equal digits to the block's LDS table instead of one per key (the library's kernel,
-// one LDS add per key and place, spends most of its 43 us at 16.7 M keys on adds that collide on one counter).
+// ---- digit counts of every place in one pass over the keys --------------------------------------------------------
+// The keys of a step arrive in the cell order of the step before, so neighbouring keys mostly agree in their upper
+// digits and often in all of them: a thread takes 16 consecutive keys at a time and adds one count per run of equal
+// digits to the block's LDS table instead of one per key (one LDS add per key and place spends most of its time on
+// adds that collide on one counter).
 #ifndef PM_COUNT_BLOCK
 #define PM_COUNT_BLOCK 1024
 #endif
@@ -70,39 +41,46 @@ using lookback_t = rocprim::detail::onesweep_lookback_state;
 #define PM_COUNT_GRID 512
 #endif
 constexpr unsigned COUNT_ITEMS = 16;
-template <unsigned RADIX>
+
+template <typename K, unsigned RADIX>
 __global__ void __launch_bounds__(PM_COUNT_BLOCK)
-k_digit_counts(const uint32_t *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t size, uint32_t /*full_blocks*/, unsigned bits)
+k_digit_counts(const K *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t size, unsigned bits)
 {
-    constexpr unsigned ITEMS = COUNT_ITEMS, MAX_PLACES = (32 + RADIX - 1) / RADIX, SIZE = 1u << RADIX;
+    constexpr unsigned ITEMS = COUNT_ITEMS, MAX_PLACES = (8 * sizeof(K) + RADIX - 1) / RADIX, SIZE = 1u << RADIX;
     static_assert(ITEMS % 4 == 0, "keys are loaded four at a time");
-    __shared__ uint32_t table[MAX_PLACES * SIZE];
+    extern __shared__ uint32_t table[];                 // places * SIZE counters
     const unsigned places = (bits + RADIX - 1) / RADIX;
+    if (places > MAX_PLACES) return;
     for (unsigned q = threadIdx.x; q < places * SIZE; q += PM_COUNT_BLOCK) table[q] = 0u;
     __syncthreads();
     // the blocks stride over the keys in chunks of PM_COUNT_BLOCK * ITEMS, so that a block's table is flushed once
     const uint64_t stride = (uint64_t)gridDim.x * PM_COUNT_BLOCK * ITEMS;
     for (uint64_t first = ((uint64_t)blockIdx.x * PM_COUNT_BLOCK + threadIdx.x) * ITEMS; first < size; first += stride) {
-        uint32_t k[ITEMS];
+        K k[ITEMS];
         const unsigned have = size - first < ITEMS ? (unsigned)(size - first) : ITEMS;
         if (have == ITEMS) {
-            const uint4 *src = (const uint4 *)(keys + first);
+            if constexpr (sizeof(K) == 4) {
+                const uint4 *src = (const uint4 *)(keys + first);
 #pragma unroll
-            for (unsigned q = 0; q < ITEMS / 4; ++q) {
-                const uint4 v = src[q];
-                k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+                for (unsigned q = 0; q < ITEMS / 4; ++q) {
+                    const uint4 v = src[q];
+                    k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (unsigned q = 0; q < ITEMS; ++q) k[q] = keys[first + q];
             }
         } else {
 #pragma unroll
-            for (unsigned q = 0; q < ITEMS; ++q) k[q] = q < have ? keys[first + q] : 0u;
+            for (unsigned q = 0; q < ITEMS; ++q) k[q] = q < have ? keys[first + q] : (K)0;
         }
         for (unsigned place = 0, bit = 0; place < places; ++place, bit += RADIX) {
             const uint32_t mask = (bits - bit < RADIX ? (1u << (bits - bit)) : SIZE) - 1u;
             uint32_t *row = table + place * SIZE;
-            uint32_t cur = (k[0] >> bit) & mask, run = 1;
+            uint32_t cur = digit_of(k[0], bit, mask), run = 1;
 #pragma unroll
             for (unsigned q = 1; q < ITEMS; ++q) {
-                const uint32_t d = (k[q] >> bit) & mask;
+                const uint32_t d = digit_of(k[q], bit, mask);
                 if (q < have) {
                     if (d == cur) ++run;
                     else { atomicAdd(row + cur, run); cur = d; run = 1; }
@@ -117,199 +95,361 @@ k_digit_counts(const uint32_t *__restrict__ keys, uint32_t *__restrict__ counts,
         if (v) atomicAdd(counts + q, v);
     }
 }
-#else
-template <unsigned RADIX>
-__global__ void __launch_bounds__(PM_HIST_BLOCK)
-k_digit_counts(const uint32_t *keys, uint32_t *counts, uint32_t size, uint32_t full_blocks, unsigned bits)
+
+// Exclusive sum over the threads of a workgroup of SORT_BLOCK threads (every thread must call it); wsum: SORT_WAVES words of LDS.
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t *wsum)
 {
-    rocprim::detail::onesweep_histograms<PM_HIST_BLOCK, PM_HIST_ITEMS, RADIX, false>(keys, counts, size, full_blocks, rocprim::identity_decomposer{}, 0u, bits);
+    const int lane = lane_id(), w = wave_id();
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int q = 0; q < w; ++q) before += wsum[q];
+    __syncthreads();                                    // wsum may be reused by the caller's next scan
+    return before + incl - v;
 }
+
+// counts[place][digit] -> number of keys whose digit at that place is smaller: one workgroup per place
+template <unsigned RADIX>
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_digit_offsets(uint32_t *__restrict__ counts)
+{
+    constexpr uint32_t SIZE = 1u << RADIX;
+    static_assert(SIZE <= SORT_BLOCK, "a thread per digit");
+    __shared__ uint32_t wsum[SORT_WAVES];
+    uint32_t *row = counts + (size_t)blockIdx.x * SIZE;
+    const uint32_t v = threadIdx.x < SIZE ? row[threadIdx.x] : 0u;
+    const uint32_t before = block_exclusive_sum(v, wsum);
+    if (threadIdx.x < SIZE) row[threadIdx.x] = before;
+}
+
+// ---- where a pass puts a pair --------------------------------------------------------------------------------------
+
+// the sorted pairs, nothing else
+template <typename K>
+struct pair_sink {
+    K *kout; uint32_t *vout;
+    __device__ __forceinline__ void operator()(const uint32_t (&dest)[SORT_ITEMS], const K (&key)[SORT_ITEMS], const uint32_t (&val)[SORT_ITEMS],
+                                               const bool (&live)[SORT_ITEMS]) const
+    {
+#pragma unroll
+        for (int i = 0; i < SORT_ITEMS; ++i)
+            if (live[i]) { kout[dest[i]] = key[i]; vout[dest[i]] = val[i]; }
+    }
+};
+
+// ---- one pass ------------------------------------------------------------------------------------------------------
+// Look-back state of (workgroup, digit): the top two bits say what the rest is -- nothing yet (0), the workgroup's
+// own count of the digit (PARTIAL), or the count of the digit in this and all earlier workgroups (PREFIX).  S is
+// 32-bit while the counts fit 30 bits, else 64-bit.
+template <typename S> struct state_bits {
+    static constexpr int SHIFT = 8 * sizeof(S) - 2;
+    static constexpr S PARTIAL = (S)1 << SHIFT, PREFIX = (S)2 << SHIFT, COUNT = PARTIAL - 1;
+};
+
+template <typename K, unsigned RADIX> constexpr size_t pass_lds_bytes()
+{
+    constexpr size_t SIZE = (size_t)1 << RADIX;
+    constexpr size_t hist = (size_t)SORT_WAVES * SIZE * sizeof(uint32_t), keys = (size_t)SORT_TILE * sizeof(K);
+    return (hist > keys ? hist : keys) + (size_t)SORT_TILE * sizeof(uint32_t) + 2 * SIZE * sizeof(uint32_t) + 32 * sizeof(uint32_t);
+}
+
+// A workgroup takes the next tile of SORT_TILE pairs (tiles are handed out by a counter, so a tile's predecessors have
+// all started), ranks its pairs by the digit at `bit` -- rank = place among the tile's pairs with that digit, in tile
+// order --, learns from the look-back chain how many pairs with each digit the earlier tiles hold, brings its pairs
+// into digit order in LDS and writes them out, each digit's pairs to consecutive addresses.
+//
+// Tile order is (wave, item, lane): wave w holds pairs w * 64 * ITEMS + i * 64 + lane.  A wave ranks one item at a
+// time: the lanes whose digits agree find each other with one ballot per digit bit, read the wave's count of the
+// digit, and the first of them adds their number to it.
+// (two workgroups per CU: 8 waves per SIMD, which caps the kernel at 64 vector registers; it needs 47)
+#ifndef PM_PASS_WAVES
+#define PM_PASS_WAVES 8
 #endif
-
-template <unsigned RADIX>
-__global__ void __launch_bounds__(PM_HIST_BLOCK)
-k_digit_offsets(uint32_t *counts)
+template <typename K, typename S, unsigned RADIX, bool COUNTED, class Sink>
+__global__ void __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(PM_PASS_WAVES)))
+k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n, const uint32_t *__restrict__ digit_base,
+             S *__restrict__ states, uint32_t *__restrict__ ticket, unsigned bit, uint32_t mask, Sink sink)
 {
-    rocprim::detail::onesweep_scan_histograms<PM_HIST_BLOCK, RADIX>(counts);
+    constexpr uint32_t SIZE = 1u << RADIX;
+    constexpr size_t HIST = (size_t)SORT_WAVES * SIZE * sizeof(uint32_t), KEYS = (size_t)SORT_TILE * sizeof(K);
+    extern __shared__ __align__(16) unsigned char lds[];
+    uint32_t *whist = (uint32_t *)lds;                  // per wave and digit: pairs seen so far, later the wave's first rank
+    K *skeys = (K *)lds;                                // the same memory, once the ranks are known
+    uint32_t *svals = (uint32_t *)(lds + (HIST > KEYS ? HIST : KEYS));
+    uint32_t *dstart = svals + SORT_TILE;               // first place of a digit in the tile's digit order
+    uint32_t *gdelta = dstart + SIZE;                   // place in the output minus place in the tile, per digit
+    uint32_t *misc = gdelta + SIZE;                     // [0] the tile, [1..] scan scratch
+    const int t = threadIdx.x, lane = lane_id(), w = wave_id();
+
+    if (t == 0) misc[0] = atomicAdd(ticket, 1u);
+    for (uint32_t q = t; q < SORT_WAVES * SIZE; q += SORT_BLOCK) whist[q] = 0u;
+    __syncthreads();
+    const uint32_t tile = misc[0];
+    const uint32_t base = tile * (uint32_t)SORT_TILE;
+    if (base >= n) return;                              // (never: the grid has exactly the tiles there are)
+    const uint32_t count = n - base < (uint32_t)SORT_TILE ? n - base : (uint32_t)SORT_TILE;
+    const uint32_t first = (uint32_t)w * (64u * SORT_ITEMS) + (uint32_t)lane;      // place in the tile of item 0
+
+    K key[SORT_ITEMS];
+    uint32_t val[SORT_ITEMS], pos[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const uint32_t q = first + 64u * i;
+        const bool live = q < count;
+        key[i] = live ? kin[base + q] : (K)0;
+        // COUNTED: the values that go in are the storage indices 0, 1, 2, ... -- nothing to read
+        val[i] = COUNTED ? base + q : (live ? vin[base + q] : 0u);
+    }
+
+    uint32_t *wh = whist + (size_t)w * SIZE;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const bool live = first + 64u * i < count;
+        const uint32_t d = digit_of(key[i], bit, mask);
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (unsigned b = 0; b < RADIX; ++b) {
+            const bool one = (d >> b) & 1u;
+            const unsigned long long set = __ballot(one);
+            peers &= one ? set : ~set;
+        }
+        if (live) {
+            const uint32_t seen = wh[d];                // every lane of the group reads the count ...
+            pos[i] = seen + (uint32_t)__popcll(peers & below);
+            if ((peers & below) == 0ull) wh[d] = seen + (uint32_t)__popcll(peers);      // ... before its first lane raises it
+        }
+    }
+    __syncthreads();
+
+    // per digit: the waves' counts become the waves' first ranks; the tile's count goes to the look-back chain
+    uint32_t total = 0;
+    if ((uint32_t)t < SIZE) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < SORT_WAVES; ++q) {
+            const uint32_t c = whist[(size_t)q * SIZE + t];
+            whist[(size_t)q * SIZE + t] = run;
+            run += c;
+        }
+        total = run;
+        __hip_atomic_store(states + (size_t)tile * SIZE + t, (S)((tile == 0 ? state_bits<S>::PREFIX : state_bits<S>::PARTIAL) | (S)total),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t before = block_exclusive_sum(total, misc + 1);
+    if ((uint32_t)t < SIZE) {
+        uint32_t earlier = 0;                           // pairs with this digit in the tiles before this one
+        if (tile > 0) {
+            uint32_t p = tile - 1;
+            for (;;) {
+                const S s = __hip_atomic_load(states + (size_t)p * SIZE + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned flag = (unsigned)(s >> state_bits<S>::SHIFT);
+                if (flag == 0u) { __builtin_amdgcn_s_sleep(1); continue; }      // that tile has not counted yet
+                earlier += (uint32_t)(s & state_bits<S>::COUNT);
+                if (flag == 2u) break;
+                --p;                                    // tile 0 always publishes a PREFIX: p never passes it
+            }
+            __hip_atomic_store(states + (size_t)tile * SIZE + t, (S)(state_bits<S>::PREFIX | (S)(earlier + total)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        dstart[t] = before;
+        gdelta[t] = digit_base[t] + earlier - before;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        if (first + 64u * i < count) {
+            const uint32_t d = digit_of(key[i], bit, mask);
+            pos[i] += dstart[d] + wh[d];
+        }
+    }
+    __syncthreads();                                    // the wave counts are not read any more: their memory takes the keys
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        if (first + 64u * i < count) { skeys[pos[i]] = key[i]; svals[pos[i]] = val[i]; }
+    }
+    __syncthreads();
+
+    uint32_t dest[SORT_ITEMS];
+    bool live[SORT_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const uint32_t q = (uint32_t)i * SORT_BLOCK + (uint32_t)t;
+        live[i] = q < count;
+        key[i] = live[i] ? skeys[q] : (K)0;
+        val[i] = live[i] ? svals[q] : 0u;
+        dest[i] = gdelta[digit_of(key[i], bit, mask)] + q;
+    }
+    sink(dest, key, val, live);
 }
 
-// VIn: where a pass reads its values -- the scratch or output array, or for the first pass a counting iterator (the
-// values that go in are the storage indices 0, 1, 2, ...: nothing to read)
-template <unsigned RADIX, class VIn>
-__global__ void __launch_bounds__(PM_SORT_BLOCK)
-k_onesweep_pass(const uint32_t *kin, uint32_t *kout, VIn vin, uint32_t *vout, uint32_t size, uint32_t *offsets_in, uint32_t *offsets_out,
-                lookback_t *lookback, unsigned bit, unsigned place_bits, uint32_t full_blocks, ticket_t ticket)
-{
-    rocprim::detail::onesweep_iteration<PM_SORT_BLOCK, PM_SORT_ITEMS, RADIX, false, rocprim::block_radix_rank_algorithm::match>(
-        kin, kout, vin, vout, size, offsets_in, offsets_out, lookback, rocprim::identity_decomposer{}, bit, place_bits, full_blocks, ticket);
-}
+// ---- host side ---------------------------------------------------------------------------------------------------
 
 constexpr size_t SORT_ALIGN = 256;
 inline size_t aligned(size_t b) { return (b + SORT_ALIGN - 1) / SORT_ALIGN * SORT_ALIGN; }
 
-// workspace: [tickets | look-back states of every pass | digit counts of every pass | spare offsets] (cleared per sort),
-// then the scratch keys and values
+// workspace: [ticket counters of every pass | digit counts of every pass | look-back states of every pass] (cleared by
+// one fill per sort), then the scratch keys and values the passes alternate through
 struct sort_plan {
-    unsigned radix, places, blocks;
-    size_t tickets, lookback, counts, spare, cleared, keys_tmp, values_tmp, bytes;
+    unsigned radix_bits, size, places, tiles;
+    bool wide;                                          // 64-bit look-back states (2^30 pairs and more)
+    size_t tickets, counts, states, cleared, keys_tmp, values_tmp, bytes;
 };
 
-template <unsigned RADIX>
-sort_plan plan_sort(size_t n, unsigned bits)
+sort_plan plan_sort(size_t n, unsigned bits, unsigned radix_bits, size_t key_bytes)
 {
     sort_plan p{};
-    p.radix = 1u << RADIX;
-    p.places = (bits + RADIX - 1) / RADIX;
-    p.blocks = (unsigned)((n + (size_t)PM_SORT_BLOCK * PM_SORT_ITEMS - 1) / ((size_t)PM_SORT_BLOCK * PM_SORT_ITEMS));
+    p.radix_bits = radix_bits;
+    p.size = 1u << radix_bits;
+    p.places = (bits + radix_bits - 1) / radix_bits;
+    p.tiles = (unsigned)((n + SORT_TILE - 1) / SORT_TILE);
+    p.wide = n >= ((size_t)1 << 30);
     p.tickets = 0;
-    p.lookback = aligned(p.places * sizeof(uint32_t));
-    p.counts = p.lookback + aligned((size_t)p.places * p.radix * p.blocks * sizeof(lookback_t));
-    p.spare = p.counts + aligned((size_t)p.places * p.radix * sizeof(uint32_t));
-    p.cleared = p.spare + aligned((size_t)p.radix * sizeof(uint32_t));
+    p.counts = aligned(p.places * sizeof(uint32_t));
+    p.states = p.counts + aligned((size_t)p.places * p.size * sizeof(uint32_t));
+    p.cleared = p.states + aligned((size_t)p.places * p.size * p.tiles * (p.wide ? 8 : 4));
     p.keys_tmp = p.cleared;
-    p.values_tmp = p.keys_tmp + aligned(n * sizeof(uint32_t));
+    p.values_tmp = p.keys_tmp + aligned(n * key_bytes);
     p.bytes = p.values_tmp + aligned(n * sizeof(uint32_t));
     return p;
 }
 
-template <unsigned RADIX>
-hipError_t own_sort_pairs(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
-                          hipStream_t s)
-{
-    const sort_plan p = plan_sort<RADIX>(n, bits);
-    if (p.bytes > tmp_bytes || n >= ((size_t)1 << 30)) return hipErrorOutOfMemory;       // one batch of the library's pass: below 2^30 pairs
-    char *w = (char *)tmp;
-    uint32_t *tickets = (uint32_t *)(w + p.tickets), *counts = (uint32_t *)(w + p.counts), *spare = (uint32_t *)(w + p.spare);
-    lookback_t *lookback = (lookback_t *)(w + p.lookback);
-    uint32_t *ktmp = (uint32_t *)(w + p.keys_tmp), *vtmp = (uint32_t *)(w + p.values_tmp);
-    hipError_t e = hipMemsetAsync(w, 0, p.cleared, s);
-    if (e != hipSuccess) return e;
-#if PM_RUN_HIST
-    const size_t per_count = (size_t)PM_COUNT_BLOCK * COUNT_ITEMS;
-    const size_t want = (n + per_count - 1) / per_count;
-    k_digit_counts<RADIX><<<(unsigned)(want < PM_COUNT_GRID ? want : PM_COUNT_GRID), PM_COUNT_BLOCK, 0, s>>>(kin, counts, (uint32_t)n, 0u, bits);
-#else
-    const size_t per_hist = (size_t)PM_HIST_BLOCK * PM_HIST_ITEMS;
-    const uint32_t hist_blocks = (uint32_t)((n + per_hist - 1) / per_hist), hist_full = (uint32_t)(n / per_hist);
-    k_digit_counts<RADIX><<<hist_blocks, PM_HIST_BLOCK, 0, s>>>(kin, counts, (uint32_t)n, hist_full, bits);
-#endif
-    k_digit_offsets<RADIX><<<p.places, PM_HIST_BLOCK, 0, s>>>(counts);
-    const size_t per_block = (size_t)PM_SORT_BLOCK * PM_SORT_ITEMS;
-    const uint32_t full_blocks = (uint32_t)(n / per_block);
-    // the last pass must end in the output: with an odd number of passes the first one goes there too
-    bool to_output = (p.places - 1) % 2 == 0, from_input = true;
-    for (unsigned place = 0, bit = 0; place < p.places; ++place, bit += RADIX) {
-        const uint32_t *ki = from_input ? kin : to_output ? ktmp : kout, *vi = from_input ? vin : to_output ? vtmp : vout;
-        uint32_t *ko = to_output ? kout : ktmp, *vo = to_output ? vout : vtmp;
-        const unsigned now = bits - bit < RADIX ? bits - bit : RADIX;
-        uint32_t *offsets = counts + (size_t)place * p.radix;
-        lookback_t *states = lookback + (size_t)place * p.radix * p.blocks;
-        const ticket_t ticket = ticket_t::create(tickets + place);
-#ifndef PM_SORT_READ_IOTA
-        if (from_input && vin == nullptr)
-            k_onesweep_pass<RADIX><<<p.blocks, PM_SORT_BLOCK, 0, s>>>(ki, ko, rocprim::counting_iterator<uint32_t>(0), vo, (uint32_t)n, offsets, spare, states,
-                                                                      bit, now, full_blocks, ticket);
-        else
-#endif
-            k_onesweep_pass<RADIX><<<p.blocks, PM_SORT_BLOCK, 0, s>>>(ki, ko, vi, vo, (uint32_t)n, offsets, spare, states, bit, now, full_blocks, ticket);
-        from_input = false;
-        to_output = !to_output;
-    }
-    return hipGetLastError();
-}
-
-__global__ void k_iota(uint32_t *__restrict__ out, int64_t n)
-{
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r < n) out[r] = (uint32_t)r;
-}
-
 // The fewest places wins: 10 bits per place where that saves a place over 9 and 8 (the 30 key bits of a 1024^3 mesh in
-// three passes instead of four: 2.43 -> 2.07 ms for the bin stage at 67 M particles), else 9 where that saves one over
-// the library's 8 (27 bits of a 512^3 mesh: three passes), else 8.
+// three passes instead of four), else 9 where that saves one over 8 (27 bits of a 512^3 mesh: three passes), else 8.
 unsigned place_bits(unsigned bits)
 {
-#ifndef PM_NO_RADIX10
     if ((bits + 9) / 10 < (bits + 8) / 9 && (bits + 9) / 10 < (bits + 7) / 8) return 10;
-#endif
     return (bits + 8) / 9 < (bits + 7) / 8 ? 9 : 8;
 }
 
-template <typename F> hipError_t with_radix(unsigned bits, F f)
+template <typename K, typename S, unsigned RADIX, bool COUNTED, class Sink>
+hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, size_t n, const uint32_t *digit_base, void *states, uint32_t *ticket, unsigned bit,
+                       unsigned now, Sink sink, int device, hipStream_t s, pm_ctx *timed)
 {
-    switch (place_bits(bits)) {
-    case 10: return f(std::integral_constant<unsigned, 10>{});
-    case 9: return f(std::integral_constant<unsigned, 9>{});
-    default: return f(std::integral_constant<unsigned, 8>{});
+    constexpr size_t lds = pass_lds_bytes<K, RADIX>();
+    auto kernel = k_radix_pass<K, S, RADIX, COUNTED, Sink>;
+    if (lds > 64 * 1024) {
+        // more LDS than a kernel gets by default: allowed once per kernel and device (a bit per device; setting it
+        // twice from two threads is harmless)
+        static std::atomic<uint64_t> allowed{0};
+        const uint64_t bit_of = 1ull << (device & 63);
+        if (!(allowed.load(std::memory_order_acquire) & bit_of)) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            allowed.fetch_or(bit_of, std::memory_order_release);
+        }
+    }
+    pm_timer timer(timed, PM_NSTAGES + PM_KERNEL_SORT_PASS);
+    kernel<<<p.tiles, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink);
+    return hipGetLastError();
+}
+
+// Sorts n (key, value) pairs by the low `bits` bits of the keys, values going in as 0, 1, 2, ... (vin == nullptr) or
+// from vin; the sorted pairs end in kout / vout -- through `last`, the sink of the final pass.
+template <typename K, typename S, unsigned RADIX, class LastSink>
+hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits, LastSink last,
+                      int device, hipStream_t s, pm_ctx *timed)
+{
+    const sort_plan p = plan_sort(n, bits, RADIX, sizeof(K));
+    if (p.bytes > tmp_bytes) return hipErrorOutOfMemory;
+    char *w = (char *)tmp;
+    uint32_t *tickets = (uint32_t *)(w + p.tickets), *counts = (uint32_t *)(w + p.counts);
+    S *states = (S *)(w + p.states);
+    K *ktmp = (K *)(w + p.keys_tmp);
+    uint32_t *vtmp = (uint32_t *)(w + p.values_tmp);
+    hipError_t e = hipMemsetAsync(w, 0, p.cleared, s);
+    if (e != hipSuccess) return e;
+    const size_t per_count = (size_t)PM_COUNT_BLOCK * COUNT_ITEMS;
+    const size_t want = (n + per_count - 1) / per_count;
+    k_digit_counts<K, RADIX><<<(unsigned)(want < PM_COUNT_GRID ? want : PM_COUNT_GRID), PM_COUNT_BLOCK, (size_t)p.places * p.size * sizeof(uint32_t), s>>>(
+        kin, counts, (uint32_t)n, bits);
+    k_digit_offsets<RADIX><<<p.places, SORT_BLOCK, 0, s>>>(counts);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // the passes alternate between the scratch and the output so that the last one ends in the output
+    bool to_output = (p.places - 1) % 2 == 0, from_input = true;
+    for (unsigned place = 0, bit = 0; place < p.places; ++place, bit += RADIX) {
+        const K *ki = from_input ? kin : to_output ? ktmp : kout;
+        const uint32_t *vi = from_input ? vin : to_output ? vtmp : vout;
+        K *ko = to_output ? kout : ktmp;
+        uint32_t *vo = to_output ? vout : vtmp;
+        const unsigned now = bits - bit < RADIX ? bits - bit : RADIX;
+        const uint32_t *base = counts + (size_t)place * p.size;
+        S *st = states + (size_t)place * p.size * p.tiles;
+        const bool counted = from_input && vin == nullptr;
+        if (place + 1 == p.places) {
+            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed)
+                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed);
+        } else {
+            const pair_sink<K> mid{ko, vo};
+            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed)
+                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed);
+        }
+        if (e != hipSuccess) return e;
+        from_input = false;
+        to_output = !to_output;
+    }
+    return hipSuccess;
+}
+
+template <typename K, class LastSink>
+hipError_t sort_dispatch(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits, LastSink last,
+                         int device, hipStream_t s, pm_ctx *timed)
+{
+    if (n == 0) return hipSuccess;
+    if (bits < 1) bits = 1;
+    const bool wide = n >= ((size_t)1 << 30);
+    auto with_state = [&](auto radix) {
+        constexpr unsigned R = decltype(radix)::value;
+        return wide ? sort_pairs<K, uint64_t, R>(tmp, tmp_bytes, kin, kout, vin, vout, n, bits, last, device, s, timed)
+                    : sort_pairs<K, uint32_t, R>(tmp, tmp_bytes, kin, kout, vin, vout, n, bits, last, device, s, timed);
+    };
+    if constexpr (sizeof(K) == 8) return with_state(std::integral_constant<unsigned, 8>{});
+    else {
+        switch (place_bits(bits)) {
+        case 10: return with_state(std::integral_constant<unsigned, 10>{});
+        case 9: return with_state(std::integral_constant<unsigned, 9>{});
+        default: return with_state(std::integral_constant<unsigned, 8>{});
+        }
     }
 }
 
-}  // namespace
-
-size_t pm_sort_tmp_bytes(int64_t cap)
+size_t tmp_bytes_for(size_t n, size_t key_bytes, unsigned max_bits)
 {
     size_t most = 0;
-    uint32_t *k = nullptr, *v = nullptr;
-    for (unsigned bits : {8u, 27u}) {
-        size_t b = 0;
-        with_radix(bits, [&](auto r) { return sort_pairs<decltype(r)::value>(nullptr, b, k, k, v, v, (size_t)cap, 32, (hipStream_t)0); });
+    for (unsigned bits = 1; bits <= max_bits; ++bits) {
+        const unsigned r = key_bytes == 8 ? 8 : place_bits(bits);
+        const size_t b = plan_sort(n, bits, r, key_bytes).bytes;
         most = b > most ? b : most;
-        // the own driver: 32 key bits at most, in places of 8 or 9 bits
-        for (unsigned kb = 1; kb <= 32; ++kb) {
-            with_radix(kb, [&](auto r) { b = plan_sort<decltype(r)::value>((size_t)cap, kb).bytes; return hipSuccess; });
-            most = b > most ? b : most;
-        }
     }
     return most;
 }
 
-hipError_t pm_sort_fill_iota(pm_ctx *c)
-{
-    k_iota<<<(unsigned)((c->cap + 255) / 256), 256, 0, c->stream>>>(c->iota, c->cap);
-    return hipGetLastError();
-}
+}  // namespace
 
+size_t pm_sort_tmp_bytes(int64_t cap) { return tmp_bytes_for((size_t)cap, sizeof(uint32_t), 32); }
+
+// key_in -> key_out, src: the cell keys in cell order and the storage slot each sorted entry came from
 hipError_t pm_sort_pairs(pm_ctx *c, int bits)
 {
-    if (c->n == 0) return hipSuccess;
-#if PM_OWN_ONESWEEP
-    // (2^30 pairs and more go through the library's call below, which cuts its passes into batches)
-    if (c->n < ((int64_t)1 << 30)) return with_radix((unsigned)bits, [&](auto r) {
-        // values in: none (the storage indices are counted, not read); PM_SORT_READ_IOTA reads them from the table instead
-#ifdef PM_SORT_READ_IOTA
-        const uint32_t *vin = c->iota;
-#else
-        const uint32_t *vin = nullptr;
-#endif
-        return own_sort_pairs<decltype(r)::value>(c->sort_tmp, c->sort_tmp_bytes, c->key_in, c->key_out, vin, c->src, (size_t)c->n, (unsigned)bits, c->stream);
-    });
-#endif
-    size_t need = 0;
-    auto run = [&](void *tmp) {
-        return with_radix((unsigned)bits, [&](auto r) {
-            return sort_pairs<decltype(r)::value>(tmp, need, c->key_in, c->key_out, c->iota, c->src, (size_t)c->n, (unsigned)bits, c->stream);
-        });
-    };
-    hipError_t e = run(nullptr);
-    if (e != hipSuccess) return e;
-    if (need > c->sort_tmp_bytes) return hipErrorOutOfMemory;
-    return run(c->sort_tmp);
+    return sort_dispatch<uint32_t>(c->sort_tmp, c->sort_tmp_bytes, c->key_in, c->key_out, nullptr, c->src, (size_t)c->n, (unsigned)bits,
+                                   pair_sink<uint32_t>{c->key_out, c->src}, c->device, c->stream, c);
 }
 
 // Particles leaving a slab: (destination slab, particle id) keys with the outbox slot as value.
-size_t pm_sort_outbox_tmp_bytes(int64_t cap)
-{
-    size_t bytes = 0;
-    uint64_t *k = nullptr;
-    uint32_t *v = nullptr;
-    rocprim::radix_sort_pairs(nullptr, bytes, k, k, rocprim::counting_iterator<uint32_t>(0), v, (size_t)cap, 0, 64, (hipStream_t)0);
-    return bytes;
-}
+size_t pm_sort_outbox_tmp_bytes(int64_t cap) { return tmp_bytes_for((size_t)cap, sizeof(uint64_t), 64); }
 
 hipError_t pm_sort_outbox(pm_ctx *c, uint32_t count)
 {
-    if (count == 0) return hipSuccess;
-    size_t need = c->outbox_tmp_bytes;
-    return rocprim::radix_sort_pairs(c->outbox_tmp, need, c->outbox_key, c->outbox_key2, rocprim::counting_iterator<uint32_t>(0), c->outbox_idx2,
-                                     (size_t)count, 0, 64, c->stream);
+    // the keys are (slab << 32) | id: 32 bits of id and as many as the slab numbers take
+    unsigned bits = 33;
+    while (bits < 64 && ((uint64_t)1 << (bits - 32)) < (uint64_t)c->nslabs) ++bits;
+    return sort_dispatch<uint64_t>(c->outbox_tmp, c->outbox_tmp_bytes, c->outbox_key, c->outbox_key2, nullptr, c->outbox_idx2, (size_t)count, bits,
+                                   pair_sink<uint64_t>{c->outbox_key2, c->outbox_idx2}, c->device, c->stream, c);
 }

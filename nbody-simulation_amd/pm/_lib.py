@@ -15,6 +15,7 @@ MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ = range(5)
 FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP = 1, 2, 4, 8
 IC_KINDS = {"uniform": 0, "two_galaxy": 1, "disk": 2}
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
+KERNELS = ("sort_pass", "reorder", "deposit_rows", "col_y_fwd", "col_x_green", "col_y_inv", "row_inv", "gather")
 
 _c_p = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -66,6 +67,7 @@ SIGNATURES = {
     "pm_slab_get_particles": (_int, [_c_p, _c_p, _c_p, _c_p]),
     "pm_slab_pitch": (_int, [_c_p]),
     "pm_stage_times": (_int, [_c_p, _c_p, _c_p]),
+    "pm_kernel_times": (_int, [_c_p, _c_p, _c_p]),
     "pm_set_flags": (_int, [_c_p, ctypes.c_uint]),
     "pm_set_stream": (_int, [_c_p, _c_p]),
     "pm_synchronize": (_int, [_c_p]),

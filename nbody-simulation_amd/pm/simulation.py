@@ -248,3 +248,11 @@ class Simulation:
         calls = np.zeros(len(L.STAGES), np.int32)
         self._ck(self.lib.pm_stage_times(self.ctx, L.ptr(ms), L.ptr(calls)))
         return {s: (float(ms[i]), int(calls[i])) for i, s in enumerate(L.STAGES)}
+
+    def kernel_times(self):
+        """{kernel: (milliseconds, launches)} of the single launches pm_kernel_times reports, since the last call
+        (needs timing=True): HIP events around each launch on the engine's stream."""
+        ms = np.zeros(len(L.KERNELS), np.float32)
+        calls = np.zeros(len(L.KERNELS), np.int32)
+        self._ck(self.lib.pm_kernel_times(self.ctx, L.ptr(ms), L.ptr(calls)))
+        return {s: (float(ms[i]), int(calls[i])) for i, s in enumerate(L.KERNELS)}

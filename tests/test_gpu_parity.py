@@ -383,6 +383,86 @@ def test_fused_step_1024(pm):
     assert np.abs(out[0][1] - out[2][1]).max() <= 5e-5 * np.abs(out[2][1]).max()
 
 
+# ---- the clustered-disk configuration itself: N = 67,108,864 on 1024^3 -------------------------------------
+
+@pytest.fixture(scope="module")
+def disk64m(pm):
+    """The exponential disk of 64M particles (drawn on the device, as bench.py --device-ic draws it) as host arrays."""
+    n, G, L = 67_108_864, 1024, 10000
+    with pm.Simulation(G, L, capacity=n) as sim:
+        sim.generate("disk", n, seed=42)
+        pos, vel = sim.positions(), sim.velocities()
+    return n, G, L, pos, vel, np.ones(n, np.float32)
+
+
+def test_disk_1024_cell_order_and_density(pm, disk64m):
+    """Whole cell order bit for bit against the oracle's keys and stable sort, mass conservation, density within the
+    deposit's bounds against the oracle's float32 and float64 deposits."""
+    n, G, L, pos, vel, mass = disk64m
+    with pm.Simulation(G, L, pos, vel, mass) as sim:
+        keys, perm = sim.cell_keys()
+        ko = O.cell_keys(pos, G, L)
+        order = O.sort_order(ko)
+        assert np.array_equal(perm, order) and np.array_equal(keys, ko[order])
+        del keys, perm, order
+        # at least 30 % of the particles inside 0.1 % of the cells: the contention this configuration is about
+        counts = np.sort(np.bincount(ko >> 10, minlength=G * G))[::-1]
+        del ko
+        assert counts[: G * G // 1000].sum() >= 0.3 * n
+        sim.deposit()
+        d = sim.density()
+    assert abs(d.astype(np.float64).sum() - n) <= 1e-6 * n
+    d64 = O.CIC_f64(pos, G, L, mass)
+    d32 = O.CIC(pos, G, L, mass)
+    tol = 2e-5 * np.abs(d32) + 1e-6 * np.abs(d32).max()
+    assert np.all(np.abs(d - d32) <= tol)
+    assert np.abs(d - d64).max() <= np.abs(d32 - d64).max() + np.finfo(np.float32).eps * np.abs(d64).max()
+
+
+def test_disk_1024_forces_and_fused_step(pm, disk64m):
+    """force_CIC bit for bit against the oracle on a 200k-particle sample (same gradient meshes); the potential against
+    the density on single Fourier modes (phi_k = rho_k / k^2, functions.py:85); no net force; and one whole step with the
+    same bits from the fused and the staged pipeline."""
+    n, G, L, pos, vel, mass = disk64m
+    dt = 0.005
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=False) as sim:
+        sim.deposit()
+        sim.solve_potential()
+        # single modes by projection, sum(f * exp(-2 pi i (a x + b y + c z) / G)): along z for all modes at once as a
+        # matrix product (float64, a group of planes at a time), then the two small remaining axes
+        modes = ((1, 0, 0), (0, 3, 2), (5, 7, 1))
+        x = np.arange(G)
+        wz = np.concatenate([[np.cos(2 * np.pi * c * x / G), -np.sin(2 * np.pi * c * x / G)] for _, _, c in modes]).T
+
+        def project(f):
+            t = np.concatenate([f[i:i + 64].reshape(-1, G).astype(np.float64) @ wz for i in range(0, G, 64)]).reshape(G, G, len(modes), 2)
+            t = t[..., 0] + 1j * t[..., 1]
+            return [np.exp(-2j * np.pi * a * x / G) @ (t[:, :, q].T * np.exp(-2j * np.pi * b * x / G)[:, None]).sum(axis=0)
+                    for q, (a, b, _) in enumerate(modes)]
+        rho, phi = project(sim.density()), project(sim.potential())
+        for (a, b, c), rho_k, phi_k in zip(modes, rho, phi):
+            k2 = sum((min(q, G - q) / G) ** 2 for q in (a, b, c))
+            assert abs(phi_k - rho_k / k2) <= 2e-5 * abs(rho_k / k2), (a, b, c)
+        sim.gradient()
+        sim.compute_forces()
+        f = sim.forces()
+        sample = np.random.default_rng(0).choice(n, 200_000, replace=False)
+        fo = O.force_CIC([sim.mesh(w) for w in (2, 3, 4)], pos[sample], G, L)
+        assert np.array_equal(f[sample], fo)
+        net = f.astype(np.float64).sum(axis=0)
+        assert np.abs(net).max() <= 1e-5 * np.abs(f.astype(np.float64)).sum(axis=0).max()
+        del f, fo
+        sim.set_particles(pos, vel, mass)
+        sim.step(dt)
+        x_staged, v_staged = sim.positions(), sim.velocities()
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+        sim.step(dt)
+        assert np.array_equal(sim.positions(), x_staged) and np.array_equal(sim.velocities(), v_staged)
+    # the particles moved as main.py:58-60 says they do: every one by its velocity times dt (float32), inside the box
+    dx = np.abs(x_staged.astype(np.float64) - (pos.astype(np.float64) + v_staged.astype(np.float64) * dt) % L)
+    assert np.minimum(dx, L - dx).max() <= 1e-6 * L and x_staged.min() >= 0 and x_staged.max() <= L
+
+
 def test_clustered_hot_cell(pm):
     """Half of the particles in one cell: the wave-cooperative run path of the deposit."""
     n, G, L = 200_000, 100, 10000

@@ -74,8 +74,14 @@ def test_bench_workloads():
     # stages are priced the same way in both tables
     f, share = bench.fused_stage_bytes(100, 1000), bench.stage_bytes(100, 1000, fused=True)
     assert all(f[s] <= share[s] for s in f) and sum(f.values()) == 64 * 100 + 40 * 1000
+    # the kernels the roofline object can name are priced like the stages they are (or are the longest part of)
     k = bench.kernel_bytes(100, 1000)
-    assert all(k[s][1] == f[s] for s in k)
+    assert k["deposit_rows"][1] == f["deposit"] and k["gather"][1] == f["gather"]
+    assert k["col_y_fwd"][1] == f["fft_fwd"] and k["col_x_green"][1] == f["green"]
+    assert k["col_y_inv"][1] + k["row_inv"][1] == f["fft_inv"]
+    assert k["sort_pass"][1] == 0 and k["reorder"][1] == 0             # cell order has no algorithmic bytes
+    from pm import _lib
+    assert set(k) == set(_lib.KERNELS)
 
 
 def test_import_galaxy_matches_golden(golden):
