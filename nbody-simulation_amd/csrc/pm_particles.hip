@@ -7,6 +7,8 @@
 // -ffp-contract=off so no product is fused into an add.
 #include "pm_internal.hpp"
 #include "pm_fft_dev.hpp"
+
+#include <atomic>
 #include "pm_cell_dev.hpp"
 
 namespace {
@@ -554,21 +556,46 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     // follows starts with the first planes -- each kernel meets the other's most recent output while caches still hold it
     const uint32_t row = (gridDim.x - 1 - blockIdx.x) * (BLOCK / 64) + (uint32_t)wave_id();
     float2 *tw = (float2 *)(lds_rows + (size_t)(BLOCK / 64) * G);
+    double *acc = lds_rows + (size_t)wave_id() * G;
+    // A wave's time goes into waiting for what it reads: the twiddle table (the block's copy in LDS), then where its
+    // four source runs lie, then the first particles.  All three are requested before the first wait, in this order.
+    constexpr int TWQ = NFFT != 0 ? (NFFT + BLOCK - 1) / BLOCK : 1;
+    float2 twv[TWQ];
     if constexpr (NFFT != 0) {
-        for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
+#pragma unroll
+        for (int q = 0; q < TWQ; ++q) {
+            const int at = (int)threadIdx.x + q * BLOCK;
+            twv[q] = at < NFFT ? twiddle[at] : make_float2(0.0f, 0.0f);
+        }
+    }
+    const bool in_range = row < R;
+    row_runs t{};
+    bool crowded = false;
+    if (in_range) {
+        t = runs_of(rs, row_unit, row, g);
+        t.longest = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (t.unit[q] != NO_UNIT) { crowded = true; t.end[q] = t.beg[q]; }     // not walked here
+            const uint32_t len = t.end[q] - t.beg[q];
+            t.longest = len > t.longest ? len : t.longest;
+        }
+    }
+    const packed_runs p(t);
+    const bool walk = in_range && t.longest != 0, packed = p.total <= PACKED_MAX;
+    light_t first{};
+    if (walk && packed) first = p.load(F, key, 0);
+    if (walk)
+        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+    if constexpr (NFFT != 0) {
+#pragma unroll
+        for (int q = 0; q < TWQ; ++q) {
+            const int at = (int)threadIdx.x + q * BLOCK;
+            if (at < NFFT) tw[at] = twv[q];
+        }
         __syncthreads();                                // the only block-wide barrier: before any wave leaves
     }
-    if (row >= R) return;
-    double *acc = lds_rows + (size_t)wave_id() * G;
-    row_runs t = runs_of(rs, row_unit, row, g);
-    bool crowded = false;
-    t.longest = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (t.unit[q] != NO_UNIT) { crowded = true; t.end[q] = t.beg[q]; }     // not walked here
-        const uint32_t len = t.end[q] - t.beg[q];
-        t.longest = len > t.longest ? len : t.longest;
-    }
+    if (!in_range) return;
     if (t.longest == 0 && !crowded) {
         emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp, g.sb);
         return;
@@ -582,13 +609,9 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         if (t.longest == 0) return;
         entry = __builtin_amdgcn_readfirstlane(entry);
     }
-    const packed_runs p(t);
-    if (p.total <= PACKED_MAX) {
-        const light_t first = p.load(F, key, 0);
-        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+    if (packed) {
         deposit_packed(F, key, p, first, G, acc);
     } else {
-        for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) deposit_chunks(F, key, t.beg[q], t.end[q], t.key0[q], q & 1, q & 2, G, acc);
     }
@@ -998,11 +1021,16 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
     const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);
-    static bool attr[64] = {};                          // per device
-    if (lds_units > 64 * 1024 && !attr[c->device & 63]) {
-        e = hipFuncSetAttribute((const void *)k_deposit_units, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_units);
-        if (e != hipSuccess) return e;
-        attr[c->device & 63] = true;
+    if (lds_units > 64 * 1024) {
+        // more LDS than a kernel gets by default: allowed once per device (a bit per device; two threads that both
+        // find it unset both set it, which is harmless)
+        static std::atomic<uint64_t> allowed{0};
+        const uint64_t bit = 1ull << (c->device & 63);
+        if (!(allowed.load(std::memory_order_acquire) & bit)) {
+            e = hipFuncSetAttribute((const void *)k_deposit_units, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_units);
+            if (e != hipSuccess) return e;
+            allowed.fetch_or(bit, std::memory_order_release);
+        }
     }
     // The units need the plan only: they are summed on the side stream while the rows are walked on this one --
     // unless recent deposits had no units at all (the count comes back to the host without anyone waiting for

@@ -404,11 +404,11 @@ def test_disk_1024_cell_order_and_density(pm, disk64m):
         ko = O.cell_keys(pos, G, L)
         order = O.sort_order(ko)
         assert np.array_equal(perm, order) and np.array_equal(keys, ko[order])
-        del keys, perm, order
         # at least 30 % of the particles inside 0.1 % of the cells: the contention this configuration is about
-        counts = np.sort(np.bincount(ko >> 10, minlength=G * G))[::-1]
-        del ko
-        assert counts[: G * G // 1000].sum() >= 0.3 * n
+        edges = np.flatnonzero(np.diff(keys)) + 1
+        counts = np.sort(np.diff(np.concatenate(([0], edges, [n]))))[::-1]
+        assert counts[: G ** 3 // 1000].sum() >= 0.3 * n
+        del keys, perm, order, ko, edges, counts
         sim.deposit()
         d = sim.density()
     assert abs(d.astype(np.float64).sum() - n) <= 1e-6 * n
