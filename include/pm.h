@@ -36,8 +36,8 @@ enum { PM_OK = 0, PM_EINVAL = 1, PM_ENOMEM = 2, PM_EHIP = 3, PM_EFFT = 4, PM_EST
 /* host dtypes of particle arrays */
 enum { PM_F32 = 0, PM_F64 = 1 };
 
-/* meshes addressable by pm_get_mesh / pm_set_mesh */
-enum { PM_MESH_DENSITY = 0, PM_MESH_POTENTIAL = 1, PM_MESH_GX = 2, PM_MESH_GY = 3, PM_MESH_GZ = 4 };
+/* meshes addressable by pm_get_mesh / pm_set_mesh; PM_SLAB_ZSPECTRUM is for pm_slab_planes only */
+enum { PM_MESH_DENSITY = 0, PM_MESH_POTENTIAL = 1, PM_MESH_GX = 2, PM_MESH_GY = 3, PM_MESH_GZ = 4, PM_SLAB_ZSPECTRUM = 5 };
 
 /* pm_create flags */
 enum {
@@ -203,12 +203,16 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
  * particles' numbers in the whole run (or NULL for 0..n-1), which travel with them between slabs. */
 int pm_slab_set_particles(pm_ctx *ctx, const float *pos, const float *vel, const float *mass, const uint32_t *ids, int64_t n);
 /* CIC (functions.py:19-70) of the owned particles into nplanes + 1 density planes: the last one is
- * plane 0 of the next slab (functions.py:56, i1 = (i + 1) % G) and has to be added there. */
+ * plane 0 of the next slab (functions.py:56, i1 = (i + 1) % G) and has to be added there.  A context created with
+ * PM_FLAG_FUSED_GRADIENT on a grid size of the hand-written transforms (512, 1024) writes every row of those planes
+ * already transformed along z, as a row of the half spectrum (no density mesh: PM_SLAB_ZSPECTRUM below); the
+ * transform is linear, so the extra plane is added to the next slab's plane 0 just the same. */
 int pm_slab_deposit(pm_ctx *ctx);
 /* Planes [first, first + count) of the context's density (nplanes + 1 planes) or potential (plane 0 =
  * mesh plane plane0 - 1, planes 1..nplanes the owned ones, then mesh planes plane0 + nplanes and + 1,
- * all modulo G) <-> a device buffer of count*G*G floats.  op 0: mesh -> buffer, 1: buffer -> mesh,
- * 2: mesh += buffer. */
+ * all modulo G) <-> a device buffer of count*G*G floats; or, with which = PM_SLAB_ZSPECTRUM, of the nplanes + 1
+ * z-transformed planes such a deposit writes <-> a buffer of count*G*pitch complex64 (2*count*G*pitch floats).
+ * op 0: mesh -> buffer, 1: buffer -> mesh, 2: mesh += buffer. */
 int pm_slab_planes(pm_ctx *ctx, int which, int first, int count, void *device_buffer, int op);
 /* compute_potential (functions.py:73-89), the transforms along z and y: dir < 0 owned density planes ->
  * half spectrum (nplanes, G, pitch); dir > 0 half spectrum -> owned potential planes. */
@@ -232,6 +236,12 @@ int pm_slab_gather_kick_drift(pm_ctx *ctx, double dt);
  * pm_slab_gather_kick_drift and the next pm_slab_deposit, outbox first. */
 int pm_slab_outbox(pm_ctx *ctx, int64_t *counts, void *device_records, int64_t capacity);
 int pm_slab_inbox(pm_ctx *ctx, const void *device_records, int64_t n);
+/* pm_slab_outbox in two halves, for a caller that exchanges the counts between the slabs on the device and reads
+ * them back once: pm_slab_outbox_counts writes counts[d], d < nslabs, and then the number of leavers that did not fit
+ * the outbox (must be 0) as nslabs + 1 int64 to DEVICE memory, on the context's stream; pm_slab_outbox_records takes
+ * the counts back from the host and writes the sorted records, reading nothing from the device. */
+int pm_slab_outbox_counts(pm_ctx *ctx, int64_t *device_counts);
+int pm_slab_outbox_records(pm_ctx *ctx, const int64_t *counts, void *device_records, int64_t capacity);
 /* Owned particles in storage order: ids (n), pos and vel (n,3); the buffers hold pm_num_particles() entries as
  * it is before the call, and pm_num_particles() after the call says how many were written (the particles
  * that left in the last drift are not among them). */

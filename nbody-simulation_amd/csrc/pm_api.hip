@@ -147,7 +147,8 @@ static int create_impl(pm_ctx *c)
     TRY(dalloc(c, &c->potential, (planes + 3) * plane));
     if (!c->slab)
         for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
-    TRY(dalloc(c, &c->spectrum, planes * G * c->g.Ghp));
+    // (a slab's deposit may leave its nplanes + 1 planes as z-transformed rows: one more plane of spectrum)
+    TRY(dalloc(c, &c->spectrum, (planes + (c->slab ? 1 : 0)) * G * c->g.Ghp));
     TRY(dalloc(c, &c->forces, 3 * cap));
     TRY(dalloc(c, &c->diag, 2 * 1024 + 4));
     HIP_TRY(c, hipMalloc(&c->stage, cap * 32 + 16));

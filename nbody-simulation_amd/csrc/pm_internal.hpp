@@ -137,12 +137,13 @@ struct pm_ctx {
     int nslabs = 1;
     bool y_in_exchange = false;         // hand-written transforms: the passes along y read / write the all-to-all buffer themselves
     bool slab_check = false;            // the next deposit verifies that every particle lies in the slab
+    bool outbox_pending = false;        // a drift has run and its leavers have not been taken out yet (pm_slab_outbox*)
     int64_t leaving = 0;                // particles with the "not mine" key in the live set (they sort to the tail)
     pm_migrant *outbox = nullptr;       // particles that left the slab in the last drift, in no particular order
     uint64_t *outbox_key = nullptr, *outbox_key2 = nullptr;     // (destination slab << 32) | particle id
     uint32_t *outbox_idx2 = nullptr;    // outbox slots in sorted order
     uint32_t *outbox_offsets = nullptr; // first sorted entry per destination slab (nslabs + 1)
-    uint32_t *outbox_count = nullptr;   // [0] entries of outbox, [1] entries that did not fit
+    uint32_t *outbox_count = nullptr;   // [0] entries of outbox, [1] entries that did not fit, [2 + d] entries bound for slab d
     int64_t outbox_cap = 0;
     void *outbox_tmp = nullptr;
     size_t outbox_tmp_bytes = 0;
@@ -223,6 +224,7 @@ hipError_t pm_launch_outbox_offsets(pm_ctx *c, uint32_t count, uint32_t *offsets
 hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count);
 hipError_t pm_launch_set_ids(pm_ctx *c, const uint32_t *ids);
 hipError_t pm_launch_export_slab(pm_ctx *c, uint32_t *ids, float *pos, float *vel);
+hipError_t pm_launch_outbox_counts(pm_ctx *c, int64_t *device_counts);
 hipError_t pm_launch_row_fft(pm_ctx *c, bool forward);
 hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles);
 int pm_fft_tiles(const pm_ctx *c);

@@ -739,6 +739,8 @@ struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
 __device__ constexpr int DI[8] = {0, 1, 0, 0, 1, 1, 0, 1}, DJ[8] = {0, 0, 1, 0, 1, 0, 1, 1}, DK[8] = {0, 0, 0, 1, 0, 1, 1, 1};
 
 // Where the particles that leave a slab go (SLAB instantiation of k_gather only).
+// count[0]: entries of the outbox, count[1]: entries that did not fit, count[2 + d]: entries bound for slab d,
+// count[2 + nslabs]: set (and never cleared) once a particle was found in a slab that does not own its cell
 struct outbox_t { pm_migrant *rec; uint64_t *key; uint32_t *count; uint32_t cap; };
 
 // SLAB: the context owns planes [i0, i0 + Gs) of the mesh; phi holds them with one plane below and two
@@ -756,7 +758,17 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     if (r >= n) return;
     const int G = g.G;
     const pm_prec<TP> p = Pin[r];
-    const cell_t c = locate(p, g);
+    cell_t c = locate(p, g);
+    if constexpr (SLAB) {
+        // A particle whose cell lies in another slab should not be here (pm_slab_inbox was handed a record that belongs
+        // elsewhere, or the outbox was never emptied).  It is noted in a word that is never cleared -- the caller sees
+        // it with the next counts -- and read against the slab's first plane, so that no access leaves the buffers.
+        const int il = c.i - g.i0;
+        if (g.Gs != G && (il < 0 || il >= g.Gs)) {
+            atomicOr(ob.count + 2 + G / g.Gs, 1u);
+            c.i = g.i0;
+        }
+    }
     const int i1 = (c.i + 1 == G) ? 0 : c.i + 1, j1 = (c.j + 1 == G) ? 0 : c.j + 1, k1 = (c.k + 1 == G) ? 0 : c.k + 1;
     const double wx[2] = {1.0 - c.dx, c.dx}, wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
     const int ii[2] = {c.i, i1}, jj[2] = {c.j, j1}, kk[2] = {c.k, k1};
@@ -870,14 +882,26 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
             uint32_t base = 0;
             if (lane_id() == leader) base = atomicAdd(ob.count, (uint32_t)__popcll(lm));
             base = __shfl(base, leader);
+            const uint32_t dest = (uint32_t)(cn.i / g.Gs);
+            bool kept = false;
             if (leaves) {
                 const uint32_t slot = base + (uint32_t)__popcll(lm & ((1ull << lane_id()) - 1ull));
-                if (slot < ob.cap) {
+                kept = slot < ob.cap;
+                if (kept) {
                     ob.rec[slot] = pm_migrant{o.x, o.y, o.z, o.m, v.x, v.y, v.z, v.id};
-                    ob.key[slot] = ((uint64_t)(uint32_t)(cn.i / g.Gs) << 32) | v.id;
+                    ob.key[slot] = ((uint64_t)dest << 32) | v.id;
                 } else {
                     atomicAdd(ob.count + 1, 1u);
                 }
+            }
+            // how many go where: one counter update per wave and destination (a wave's leavers mostly share one)
+            unsigned long long todo = __ballot(kept);
+            while (todo) {
+                const int first = __ffsll((long long)todo) - 1;
+                const uint32_t d = (uint32_t)__shfl((int)dest, first);
+                const unsigned long long same = __ballot(kept && dest == d);
+                if (lane_id() == first) atomicAdd(ob.count + 2 + d, (uint32_t)__popcll(same));
+                todo &= ~same;
             }
         }
     }
@@ -923,6 +947,15 @@ __global__ void k_append(const pm_migrant *__restrict__ src, pm_prec<float> *__r
     P[at + r] = p;
     V[at + r] = pm_vrec<float>{m.vx, m.vy, m.vz, m.id};
     key[at + r] = cell_key(locate(p, g), g);
+}
+
+// per-destination counts as 64-bit integers, counts[d], d < nslabs; then counts[nslabs] = the overflow count, plus
+// 2^32 if a particle was ever found in a slab that does not own its cell
+__global__ void k_outbox_counts(const uint32_t *__restrict__ count, int nslabs, int64_t *__restrict__ out)
+{
+    const int d = blockIdx.x * BLOCK + threadIdx.x;
+    if (d < nslabs) out[d] = (int64_t)count[2 + d];
+    else if (d == nslabs) out[d] = (int64_t)count[1] + ((int64_t)count[2 + nslabs] << 32);
 }
 
 __global__ void k_export_slab(const pm_prec<float> *__restrict__ P, const pm_vrec<float> *__restrict__ V, const uint32_t *__restrict__ vmap,
@@ -1182,5 +1215,11 @@ hipError_t pm_launch_export_slab(pm_ctx *c, uint32_t *ids, float *pos, float *ve
 {
     if (c->n == 0) return hipSuccess;
     k_export_slab<<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pf[c->cur], c->vf[c->vcur], c->v_stale ? c->src : nullptr, ids, pos, vel, c->n);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_outbox_counts(pm_ctx *c, int64_t *device_counts)
+{
+    k_outbox_counts<<<grid_for(c->nslabs + 1), BLOCK, 0, c->stream>>>(c->outbox_count, c->nslabs, device_counts);
     return hipGetLastError();
 }

@@ -50,6 +50,11 @@ int need_slab(pm_ctx *c)
     return PM_OK;
 }
 
+// the words a drift starts from zero: outbox entries, overflow, entries per destination (one more word behind them is sticky)
+size_t outbox_count_bytes(const pm_ctx *c) { return (size_t)(2 + c->nslabs) * sizeof(uint32_t); }
+
+bool spectral_deposit(const pm_ctx *c) { return c->fft_custom && (c->flags & PM_FLAG_FUSED_GRADIENT); }
+
 int bits_for(int64_t M)
 {
     int b = 1;
@@ -110,7 +115,8 @@ int ensure_binned(pm_ctx *c)
     HIP_TRY(c, pm_settle_velocities(c));
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
     c->keys_fresh = false;
-    HIP_TRY(c, pm_sort_pairs(c, bits_for((int64_t)c->g.Gs * c->g.G * c->g.G + 1)));
+    // one key more than the slab has cells: "not mine" -- which a slab that is the whole mesh never hands out
+    HIP_TRY(c, pm_sort_pairs(c, bits_for((int64_t)c->g.Gs * c->g.G * c->g.G + (c->g.Gs != c->g.G ? 1 : 0))));
     HIP_TRY(c, pm_launch_reorder(c));
     HIP_TRY(c, pm_launch_row_start(c));
     c->n -= c->leaving;         // they carry the last key: the tail of the cell order
@@ -133,7 +139,10 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
     }
     // the hand-written transforms cover whole groups of 16 rows
     if (pm_fft_custom_supported(grid_size) && ((int64_t)nplanes * grid_size) % 16 != 0) flags |= PM_FLAG_ROCFFT_ONLY;
-    pm_ctx *c = pm_create_planes(grid_size, box_size, n_capacity, device, flags & ~(unsigned)PM_FLAG_FUSED_GRADIENT, plane0, nplanes, true);
+    // PM_FLAG_FUSED_GRADIENT on a slab: the deposit leaves z-transformed rows (hand-written transforms only); the
+    // gradient is always taken inside the gather
+    if (!pm_fft_custom_supported(grid_size) || (flags & PM_FLAG_ROCFFT_ONLY)) flags &= ~(unsigned)PM_FLAG_FUSED_GRADIENT;
+    pm_ctx *c = pm_create_planes(grid_size, box_size, n_capacity, device, flags, plane0, nplanes, true);
     if (!c) return nullptr;
     c->y_in_exchange = c->fft_custom && (nplanes & (nplanes - 1)) == 0;
     auto setup = [&]() -> int {
@@ -144,8 +153,8 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
         HIP_TRY(c, hipMalloc((void **)&c->outbox_key2, (size_t)c->outbox_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->outbox_idx2, (size_t)c->outbox_cap * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void **)&c->outbox_offsets, (size_t)(c->nslabs + 1) * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void **)&c->outbox_count, 2 * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemset(c->outbox_count, 0, 2 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void **)&c->outbox_count, outbox_count_bytes(c) + sizeof(uint32_t)));
+        HIP_TRY(c, hipMemset(c->outbox_count, 0, outbox_count_bytes(c) + sizeof(uint32_t)));
         c->outbox_tmp_bytes = pm_sort_outbox_tmp_bytes(c->outbox_cap);
         HIP_TRY(c, hipMalloc(&c->outbox_tmp, c->outbox_tmp_bytes + 16));
         if (!c->fft_custom) TRY(make_plans(c));
@@ -171,8 +180,9 @@ int pm_slab_set_particles(pm_ctx *c, const float *pos, const float *vel, const f
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->leaving = 0;
+    c->outbox_pending = false;
     c->slab_check = true;
-    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, outbox_count_bytes(c), c->stream));
     return PM_OK;
 }
 
@@ -181,6 +191,7 @@ int pm_slab_set_particles(pm_ctx *c, const float *pos, const float *vel, const f
 int pm_slab_deposit(pm_ctx *c)
 {
     TRY(need_slab(c));
+    if (c->outbox_pending) return fail(c, PM_ESTATE, "pm_slab_outbox (or pm_slab_outbox_records) must follow pm_slab_gather_kick_drift before the next deposit");
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(ensure_binned(c));
     if (c->slab_check) {
@@ -190,7 +201,7 @@ int pm_slab_deposit(pm_ctx *c)
         if ((int64_t)mine != c->n) return fail(c, PM_EINVAL, std::to_string(c->n - (int64_t)mine) + " particles given to this slab lie in other slabs");
         c->slab_check = false;
     }
-    HIP_TRY(c, pm_launch_deposit(c, false));
+    HIP_TRY(c, pm_launch_deposit(c, spectral_deposit(c)));
     return PM_OK;
 }
 
@@ -200,12 +211,18 @@ int pm_slab_deposit(pm_ctx *c)
 int pm_slab_planes(pm_ctx *c, int which, int first, int count, void *device_buffer, int op)
 {
     TRY(need_slab(c));
-    const int limit = which == PM_MESH_DENSITY ? c->g.Gs + 1 : c->g.Gs + 3;
-    if ((which != PM_MESH_DENSITY && which != PM_MESH_POTENTIAL) || first < 0 || count < 0 || first + count > limit || !device_buffer || op < 0 || op > 2)
+    const int limit = which == PM_MESH_POTENTIAL ? c->g.Gs + 3 : c->g.Gs + 1;
+    if ((which != PM_MESH_DENSITY && which != PM_MESH_POTENTIAL && which != PM_SLAB_ZSPECTRUM) || first < 0 || count < 0 || first + count > limit ||
+        !device_buffer || op < 0 || op > 2)
         return fail(c, PM_EINVAL, "pm_slab_planes: bad mesh, plane range, buffer or op");
+    if (which == PM_SLAB_ZSPECTRUM && !spectral_deposit(c))
+        return fail(c, PM_ESTATE, "pm_slab_planes: this context's deposit writes density planes (PM_MESH_DENSITY), not z-transformed ones");
+    if (which == PM_MESH_DENSITY && spectral_deposit(c))
+        return fail(c, PM_ESTATE, "pm_slab_planes: this context's deposit writes z-transformed planes (PM_SLAB_ZSPECTRUM), no density mesh");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t plane = (size_t)c->g.G * c->g.G;
-    float *mesh = (which == PM_MESH_DENSITY ? c->density : c->potential) + (size_t)first * plane;
+    // a plane of the half spectrum is G rows of pitch complex64 = 2 G pitch floats (the padding of the rows travels along)
+    const size_t plane = which == PM_SLAB_ZSPECTRUM ? 2 * (size_t)c->g.G * c->g.Ghp : (size_t)c->g.G * c->g.G;
+    float *mesh = (which == PM_MESH_DENSITY ? c->density : which == PM_MESH_POTENTIAL ? c->potential : (float *)c->spectrum) + (size_t)first * plane;
     const size_t bytes = (size_t)count * plane * sizeof(float);
     if (op == 0) HIP_TRY(c, hipMemcpyAsync(device_buffer, mesh, bytes, hipMemcpyDeviceToDevice, c->stream));
     else if (op == 1) HIP_TRY(c, hipMemcpyAsync(mesh, device_buffer, bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -225,7 +242,8 @@ int pm_slab_fft2(pm_ctx *c, int dir)
     if (c->fft_custom) {
         // (with y_in_exchange the passes along y belong to pm_slab_pack / pm_slab_unpack)
         if (dir < 0) {
-            HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density, nullptr, c->spectrum, c->g.Gs));
+            // (a deposit that writes z-transformed rows has done the transform along z already)
+            if (!spectral_deposit(c)) HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density, nullptr, c->spectrum, c->g.Gs));
             if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, -1, c->spectrum, c->g.Gs));
         } else {
             if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, 1, c->spectrum, c->g.Gs));
@@ -288,36 +306,66 @@ int pm_slab_gather_kick_drift(pm_ctx *c, double dt)
     if (!c->pf[0]) return fail(c, PM_ESTATE, "no particles");
     if (c->pos_f64 || c->vel_f64) return fail(c, PM_ESTATE, "slab contexts hold float32 particles");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, outbox_count_bytes(c), c->stream));
     HIP_TRY(c, pm_launch_gather(c, dt, true, false, true));
     c->binned = false; c->have_forces = false; c->keys_fresh = true;
+    c->outbox_pending = true;       // the leavers are still in the live set until the outbox has been taken
     return PM_OK;
 }
 
-// The particles that left in the last drift, sorted by (destination slab, id), as 32-byte records
-// {x, y, z, m, vx, vy, vz, id} in device_records; counts[d] = how many go to slab d (host, nslabs entries).
+// How many particles left in the last drift for each slab, as nslabs + 1 int64 in DEVICE memory: counts[d] for
+// destination d, then the number that did not fit the outbox (must be 0).  Queued on the context's stream.
+int pm_slab_outbox_counts(pm_ctx *c, int64_t *device_counts)
+{
+    TRY(need_slab(c));
+    if (!device_counts) return fail(c, PM_EINVAL, "NULL device_counts");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, pm_launch_outbox_counts(c, device_counts));
+    TRY(done(c));
+    return PM_OK;
+}
+
+// The leavers as 32-byte records {x, y, z, m, vx, vy, vz, id} sorted by (destination slab, id) into device_records,
+// given the counts pm_slab_outbox_counts reported (host, nslabs entries): nothing is read back from the device here.
+int pm_slab_outbox_records(pm_ctx *c, const int64_t *counts, void *device_records, int64_t capacity)
+{
+    TRY(need_slab(c));
+    if (!counts) return fail(c, PM_EINVAL, "NULL counts");
+    int64_t total = 0;
+    for (int d = 0; d < c->nslabs; ++d) {
+        if (counts[d] < 0) return fail(c, PM_EINVAL, "negative count");
+        total += counts[d];
+    }
+    if (total > c->outbox_cap) return fail(c, PM_EINVAL, "more records than the outbox holds");
+    if (total > capacity) return fail(c, PM_EINVAL, "device_records too small for " + std::to_string(total) + " records");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->leaving = total;
+    c->outbox_pending = false;
+    if (total) {
+        if (!device_records) return fail(c, PM_EINVAL, "NULL device_records");
+        HIP_TRY(c, pm_sort_outbox(c, (uint32_t)total));
+        HIP_TRY(c, pm_launch_pack_outbox(c, (uint32_t)total, (pm_migrant *)device_records));
+    }
+    TRY(done(c));
+    return PM_OK;
+}
+
+// The two calls above in one, with the counts read back here (the host waits for the drift): counts[d] = how many go
+// to slab d (host, nslabs entries).
 int pm_slab_outbox(pm_ctx *c, int64_t *counts, void *device_records, int64_t capacity)
 {
     TRY(need_slab(c));
     if (!counts) return fail(c, PM_EINVAL, "NULL counts");
     HIP_TRY(c, hipSetDevice(c->device));
-    uint32_t h[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(h, c->outbox_count, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> h((size_t)c->nslabs + 2, 0u);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->outbox_count, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> sticky(1, 0u);
+    HIP_TRY(c, hipMemcpy(sticky.data(), c->outbox_count + 2 + c->nslabs, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (sticky[0]) return fail(c, PM_ESTATE, "a particle was found in this slab whose cell belongs to another (a record delivered to the wrong slab)");
     if (h[1]) return fail(c, PM_ENOMEM, "outbox overflow: " + std::to_string(h[0]) + " particles left the slab in one step");
-    if ((int64_t)h[0] > capacity) return fail(c, PM_EINVAL, "device_records too small for " + std::to_string(h[0]) + " records");
-    c->leaving = h[0];
-    std::vector<uint32_t> off((size_t)c->nslabs + 1, 0u);
-    if (h[0]) {
-        if (!device_records) return fail(c, PM_EINVAL, "NULL device_records");
-        HIP_TRY(c, pm_sort_outbox(c, h[0]));
-        HIP_TRY(c, pm_launch_pack_outbox(c, h[0], (pm_migrant *)device_records));
-        HIP_TRY(c, pm_launch_outbox_offsets(c, h[0], c->outbox_offsets));
-        HIP_TRY(c, hipMemcpyAsync(off.data(), c->outbox_offsets, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    for (int d = 0; d < c->nslabs; ++d) counts[d] = (int64_t)off[d + 1] - (int64_t)off[d];
-    return PM_OK;
+    for (int d = 0; d < c->nslabs; ++d) counts[d] = (int64_t)h[2 + d];
+    return pm_slab_outbox_records(c, counts, device_records, capacity);
 }
 
 // Particles arriving from other slabs (records as pm_slab_outbox writes them) join the live set.
@@ -325,6 +373,7 @@ int pm_slab_inbox(pm_ctx *c, const void *device_records, int64_t n)
 {
     TRY(need_slab(c));
     if (n < 0 || (n > 0 && !device_records)) return fail(c, PM_EINVAL, "bad inbox");
+    if (c->outbox_pending) return fail(c, PM_ESTATE, "pm_slab_inbox belongs behind pm_slab_outbox (or pm_slab_outbox_records)");
     if (c->n + n > c->cap) return fail(c, PM_ENOMEM, "particle capacity exceeded: " + std::to_string(c->n + n) + " > " + std::to_string(c->cap));
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->v_stale) return fail(c, PM_ESTATE, "pm_slab_inbox belongs between the drift and the next deposit");
@@ -342,6 +391,7 @@ int pm_slab_get_particles(pm_ctx *c, uint32_t *ids, float *pos, float *vel)
 {
     TRY(need_slab(c));
     if (!ids || !pos || !vel) return fail(c, PM_EINVAL, "NULL buffer");
+    if (c->outbox_pending) return fail(c, PM_ESTATE, "the last drift's leavers are still among the particles: take the outbox first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->leaving) TRY(ensure_binned(c));
     const size_t n = (size_t)c->n;

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PM_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libpm.so")
 
 PM_F32, PM_F64 = 0, 1
-MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ = range(5)
+MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ, SLAB_ZSPECTRUM = range(6)
 FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP = 1, 2, 4, 8
 IC_KINDS = {"uniform": 0, "two_galaxy": 1, "disk": 2}
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
@@ -64,6 +64,8 @@ SIGNATURES = {
     "pm_slab_gather_kick_drift": (_int, [_c_p, _dbl]),
     "pm_slab_outbox": (_int, [_c_p, _c_p, _c_p, _i64]),
     "pm_slab_inbox": (_int, [_c_p, _c_p, _i64]),
+    "pm_slab_outbox_counts": (_int, [_c_p, _c_p]),
+    "pm_slab_outbox_records": (_int, [_c_p, _c_p, _c_p, _i64]),
     "pm_slab_get_particles": (_int, [_c_p, _c_p, _c_p, _c_p]),
     "pm_slab_pitch": (_int, [_c_p]),
     "pm_stage_times": (_int, [_c_p, _c_p, _c_p]),

@@ -42,7 +42,9 @@ class HipSlabEngine:
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
         self.cap = int(capacity)
-        self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, 0, self.i0, self.Gs)
+        # FLAG_FUSED_GRADIENT on a slab: where the hand-written transforms apply, the deposit writes its planes already
+        # transformed along z (no density mesh); elsewhere the flag changes nothing
+        self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, _lib.FLAG_FUSED_GRADIENT, self.i0, self.Gs)
         if not self.ctx:
             raise _lib.PMError("pm_create_slab failed: " + (self.lib.pm_last_error(None) or b"?").decode())
         # the library works on torch's current stream: its kernels, torch's copies and the collectives order themselves
@@ -51,6 +53,10 @@ class HipSlabEngine:
         f32 = dict(dtype=torch.float32, device=self.device)
         self._blocks = [torch.empty((self.Gs * self.G * self.pitch, 2), **f32) for _ in range(2)]
         self._records = torch.empty((self.cap // 4 + 1024, 8), **f32)
+        self._counts = torch.zeros(self.world + 1, dtype=torch.int64, device=self.device)
+        # what the deposit leaves: z-transformed planes (G rows of `pitch` complex64) or density planes (G rows of G floats)
+        probe = torch.empty(2 * self.G * self.pitch, **f32)
+        self.spectral = self.lib.pm_slab_planes(self.ctx, _lib.SLAB_ZSPECTRUM, 0, 1, probe.data_ptr(), 0) == 0
 
     def close(self):
         if self.ctx:
@@ -95,6 +101,20 @@ class HipSlabEngine:
         self._sync()
         self._check(self.lib.pm_slab_planes(self.ctx, which, first, planes.shape[0], planes.data_ptr(), 2 if add else 1))
 
+    def ghost_out(self):
+        """The plane the deposit wrote beyond the slab (it belongs to the next slab) as a flat float32 tensor."""
+        if not self.spectral:
+            return self.planes_out(_lib.MESH_DENSITY, self.Gs, 1).reshape(-1)
+        out = torch.empty(2 * self.G * self.pitch, dtype=torch.float32, device=self.device)
+        self._check(self.lib.pm_slab_planes(self.ctx, _lib.SLAB_ZSPECTRUM, self.Gs, 1, out.data_ptr(), 0))
+        return out
+
+    def ghost_in(self, plane):
+        """Add the previous slab's extra plane to this slab's first one."""
+        plane = plane.to(self.device, torch.float32).contiguous()
+        which = _lib.SLAB_ZSPECTRUM if self.spectral else _lib.MESH_DENSITY
+        self._check(self.lib.pm_slab_planes(self.ctx, which, 0, 1, plane.data_ptr(), 2))
+
     def fft2(self, direction):
         self._check(self.lib.pm_slab_fft2(self.ctx, direction))
 
@@ -127,6 +147,19 @@ class HipSlabEngine:
         self._check(self.lib.pm_slab_outbox(self.ctx, counts, self._records.data_ptr(), self._records.shape[0]))
         counts = [int(c) for c in counts]
         return counts, self._records[:sum(counts)]
+
+    def outbox_counts(self):
+        """int64 tensor on the device, world + 1 entries: leavers per destination rank, then a word that must be 0 (leavers
+        that did not fit the outbox; + 2^32 once a particle was found in a slab that does not own its cell).  Nothing
+        waits for the drift here."""
+        self._check(self.lib.pm_slab_outbox_counts(self.ctx, self._counts.data_ptr()))
+        return self._counts
+
+    def outbox_records(self, counts):
+        """The leavers' records (n, 8) float32, sorted by (destination, id), given their counts per destination (host)."""
+        arr = (ctypes.c_int64 * self.world)(*[int(c) for c in counts])
+        self._check(self.lib.pm_slab_outbox_records(self.ctx, arr, self._records.data_ptr(), self._records.shape[0]))
+        return self._records[:int(sum(counts))]
 
     def inbox(self, records):
         records = records.to(self.device, torch.float32).contiguous()
@@ -188,6 +221,55 @@ class _Comm:
         else:
             dist.all_to_all_single(recv, send, group=self.group)
 
+    def shift(self, to_next, to_prev, from_prev_size, from_next_size):
+        """Flat tensors to the next and to the previous rank of the ring; returns what the previous and the next rank
+        sent here, (from_prev, from_next).  Point-to-point: two sends and two receives posted as one batch (over RCCL one
+        grouped call on the two links to the neighbours), not a collective over all ranks.  With two ranks the next and
+        the previous rank are the same one: sends and receives pair up in the order they are posted, "to next" first."""
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        if self.world == 1:
+            if self.always and self.on:         # one rank talking to itself through the backend: the collective path
+                got = self.all_to_all([torch.cat([to_next.reshape(-1), to_prev.reshape(-1)])], [from_prev_size + from_next_size])[0]
+                return got[:from_prev_size], got[from_prev_size:]
+            return to_next.reshape(-1).clone(), to_prev.reshape(-1).clone()
+        device, dtype = to_next.device, to_next.dtype
+        stage = self.stage_on_host and to_next.is_cuda
+        where = "cpu" if stage else device
+        send_n, send_p = to_next.reshape(-1).contiguous(), to_prev.reshape(-1).contiguous()
+        if stage:
+            send_n, send_p = send_n.cpu(), send_p.cpu()
+        from_prev = torch.empty(from_prev_size, dtype=dtype, device=where)
+        from_next = torch.empty(from_next_size, dtype=dtype, device=where)
+        ops = []
+        if send_n.numel():
+            ops.append(dist.P2POp(dist.isend, send_n, nxt, group=self.group))
+        if send_p.numel():
+            ops.append(dist.P2POp(dist.isend, send_p, prv, group=self.group))
+        if from_prev_size:
+            ops.append(dist.P2POp(dist.irecv, from_prev, prv, group=self.group))
+        if from_next_size:
+            ops.append(dist.P2POp(dist.irecv, from_next, nxt, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if stage:
+            from_prev, from_next = from_prev.to(device), from_next.to(device)
+        return from_prev, from_next
+
+    def exchange_counts(self, counts):
+        """counts[p] = what goes to rank p (int64 tensor, on the device for RCCL) -> what every rank p sends here."""
+        if self.world == 1 and not (self.always and self.on):
+            return counts.clone()
+        if self.stage_on_host and counts.is_cuda:
+            s, r = counts.cpu(), torch.empty(counts.shape, dtype=counts.dtype)
+            dist.all_to_all_single(r, s, group=self.group)
+            return r.to(counts.device)
+        if self.backend == "nccl" and not counts.is_cuda:
+            return self.exchange_counts(counts.cuda()).cpu()
+        recv = torch.empty_like(counts)
+        dist.all_to_all_single(recv, counts.contiguous(), group=self.group)
+        return recv
+
     def barrier(self):
         if self.on:
             dist.barrier(group=self.group)
@@ -248,50 +330,36 @@ class SlabSimulation:
     def __exit__(self, *exc):
         self.close()
 
-    # -- exchanges -----------------------------------------------------------------------------------
-
-    def _neighbours(self, to_next, to_prev, from_prev_size, from_next_size):
-        """Send flat tensors to the next and the previous rank; returns (from_prev, from_next)."""
-        world = self.comm.world
-        empty = to_next.new_empty(0)
-        chunks, sizes = [empty] * world, [0] * world
-        # with two ranks the next and the previous rank are the same one: what goes "to next" comes first
-        chunks[self.next] = to_next.reshape(-1)
-        chunks[self.prev] = torch.cat([chunks[self.prev], to_prev.reshape(-1)]) if self.prev == self.next else to_prev.reshape(-1)
-        sizes[self.prev] += from_prev_size
-        sizes[self.next] += from_next_size
-        got = self.comm.all_to_all(chunks, sizes)
-        if self.prev == self.next:
-            g = got[self.prev]
-            return g[:from_prev_size], g[from_prev_size:]
-        return got[self.prev], got[self.next]
-
     def step(self, dt, nsteps=1):
         for _ in range(nsteps):
             self._step(dt)
 
     def _step(self, dt):
-        e, G, Gs, world = self.engine, self.G, self.Gs, self.comm.world
+        e, G, Gs, world, comm = self.engine, self.G, self.Gs, self.comm.world, self.comm
         plane = G * G
         mark = self._mark
         mark("start")
         # deposit; the plane beyond the slab belongs to the next rank (functions.py:56: i1 = (i + 1) % G)
         e.deposit()
         mark("deposit")
-        ghost = e.planes_out(0, Gs, 1)
-        from_prev, _ = self._neighbours(ghost, ghost.new_empty(0), plane, 0)
-        e.planes_in(0, 0, from_prev.reshape(1, G, G), add=True)
+        ghost = e.ghost_out()
+        from_prev, _ = comm.shift(ghost, ghost.new_empty(0), ghost.numel(), 0)
+        e.ghost_in(from_prev)
         mark("density_halo")
         # compute_potential (functions.py:73-89)
         e.fft2(-1)
         blocks = e.pack()
-        spec_t = e.transposed_buffer()
         mark("fft_zy")
-        self.comm.all_to_all_equal(blocks.reshape(-1), spec_t.reshape(-1))
+        if world == 1 and not (comm.always and comm.on):
+            spec_t = blocks                         # one slab: the blocks are the transposed spectrum already
+        else:
+            spec_t = e.transposed_buffer()
+            comm.all_to_all_equal(blocks.reshape(-1), spec_t.reshape(-1))
         mark("transpose")
         e.solve_x(spec_t)
         mark("solve_x")
-        self.comm.all_to_all_equal(spec_t.reshape(-1), blocks.reshape(-1))
+        if spec_t is not blocks:
+            comm.all_to_all_equal(spec_t.reshape(-1), blocks.reshape(-1))
         mark("transpose_back")
         e.unpack(blocks)
         e.fft2(+1)
@@ -299,22 +367,26 @@ class SlabSimulation:
         # potential planes beside the slab: one below (from the previous rank), two above (from the next rank)
         to_next = e.planes_out(1, Gs, 1)            # my last owned plane
         to_prev = e.planes_out(1, 1, 2)             # my first two owned planes
-        below, above = self._neighbours(to_next, to_prev, plane, 2 * plane)
+        below, above = comm.shift(to_next, to_prev, plane, 2 * plane)
         e.planes_in(1, 0, below.reshape(1, G, G))
         e.planes_in(1, Gs + 1, above.reshape(2, G, G))
         mark("potential_halo")
-        # gradient, gather, kick, drift (main.py:54-60); then the particles that changed slab
+        # gradient, gather, kick, drift (main.py:54-60); then the particles that changed slab: how many go where is
+        # exchanged between the ranks before anyone reads it, so the host waits for the device once per step
         e.gather_kick_drift(dt)
         mark("gather_kick_drift")
-        counts, records = e.outbox()
+        mine = e.outbox_counts()                    # world + 1 entries, where the engine's data lives
+        theirs = comm.exchange_counts(mine[:world])
+        both = torch.cat([mine, theirs]).cpu().tolist()
+        counts, trouble, incoming = both[:world], both[world], both[world + 1:]
+        if trouble:
+            raise _lib.PMError("particle migration: " + ("a particle was delivered to a slab that does not own its cell"
+                                                          if trouble >> 32 else f"{trouble} leavers did not fit the outbox"))
+        records = e.outbox_records(counts)
         flat = records.reshape(-1)
-        c = torch.tensor(counts, dtype=torch.int64)
-        incoming = self.comm.all_to_all([c[p:p + 1] for p in range(world)], [1] * world)
-        incoming = [int(t[0]) for t in incoming]
         offs = np.concatenate(([0], np.cumsum(counts))) * 8
-        got = self.comm.all_to_all([flat[offs[p]:offs[p + 1]] for p in range(world)], [8 * k for k in incoming])
-        arrivals = torch.cat(got).reshape(-1, 8)
-        e.inbox(arrivals)
+        got = comm.all_to_all([flat[offs[p]:offs[p + 1]] for p in range(world)], [8 * k for k in incoming])
+        e.inbox(torch.cat(got).reshape(-1, 8))
         mark("migration")
 
     def particles(self):

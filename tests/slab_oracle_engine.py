@@ -71,6 +71,12 @@ class OracleSlabEngine:
         else:
             m[first:first + a.shape[0]] = a
 
+    def ghost_out(self):
+        return self.planes_out(0, self.Gs, 1).reshape(-1)
+
+    def ghost_in(self, plane):
+        self.planes_in(0, 0, plane.reshape(1, self.G, self.G), add=True)
+
     def fft2(self, direction):
         if direction < 0:
             self.spec = sfft.rfft2(self.density[:self.Gs], axes=(1, 2)).astype(np.complex64)
@@ -131,6 +137,13 @@ class OracleSlabEngine:
         rec[:, 4:7] = v
         rec[:, 7] = ids.view(np.float32)
         return self._counts, torch.from_numpy(rec)
+
+    def outbox_counts(self):
+        return torch.tensor(self._counts + [0], dtype=torch.int64)
+
+    def outbox_records(self, counts):
+        assert [int(c) for c in counts] == self._counts
+        return self.outbox()[1]
 
     def inbox(self, records):
         r = records.numpy().reshape(-1, 8)
