@@ -16,7 +16,9 @@
 #include "pm_internal.hpp"
 #include "pm_fft_dev.hpp"
 
+#include <atomic>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -56,7 +58,7 @@ struct col_pass {
     int64_t block_stride;   // Gs * Gs * pitch
 };
 
-// Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 8 at N = 512, 16 at N = 1024).  A column is
+// Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 2, 4, 8, 16 at N = 128, 256, 512, 1024).  A column is
 // worked on by TPC = N / EPT threads, each holding EPT of its elements; a block is 16 columns = 16 TPC threads
 // (512 or 1024 threads: more waves per CU overlap one tile's loads with another's butterflies better than the 32
 // elements per thread that the registers would allow).
@@ -305,47 +307,58 @@ k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, con
 template <int N, int DIR, bool GREEN, int BLK = 0>
 hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
 {
-    static bool attr[64] = {};                       // the attribute is per device
-    const int dev = c->device & 63;
-    if (!attr[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N, DIR, GREEN>::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr[dev] = true;
+    if (col_plan<N, DIR, GREEN>::LDS_BYTES > 64 * 1024) {
+        // more LDS than a kernel gets by default: allowed once per kernel and device (a bit per device; two threads
+        // that both find it unset both set it, which is harmless)
+        static std::atomic<uint64_t> allowed{0};
+        const uint64_t bit = 1ull << (c->device & 63);
+        if (!(allowed.load(std::memory_order_acquire) & bit)) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_col_fft<N, DIR, GREEN, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_plan<N, DIR, GREEN>::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            allowed.fetch_or(bit, std::memory_order_release);
+        }
     }
     k_col_fft<N, DIR, GREEN, BLK><<<blocks * (COLS / col_plan<N, DIR, GREEN>::C), col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(p, c->twiddle);
     return hipGetLastError();
 }
 
+// f(std::integral_constant<int, G>) for the grid sizes the hand-written transforms are built for
+template <typename F> hipError_t with_grid(int G, F f)
+{
+    switch (G) {
+    case 128: return f(std::integral_constant<int, 128>{});
+    case 256: return f(std::integral_constant<int, 256>{});
+    case 512: return f(std::integral_constant<int, 512>{});
+    case 1024: return f(std::integral_constant<int, 1024>{});
+    default: return hipErrorInvalidValue;
+    }
+}
+
 // dir < 0 forward, > 0 inverse, 0: forward, Green multiply, inverse
 hipError_t launch_col_any(pm_ctx *c, int dir, const col_pass &p, int blocks)
 {
-    if (dir == 0 && p.soft != 0.0f)
-        return c->g.G == 512 ? launch_col<512, -1, true, 3>(c, p, blocks) : launch_col<1024, -1, true, 3>(c, p, blocks);
-    if (c->g.G == 512) {
-        if (dir == 0) return launch_col<512, -1, true>(c, p, blocks);
-        return dir < 0 ? launch_col<512, -1, false>(c, p, blocks) : launch_col<512, 1, false>(c, p, blocks);
-    }
-    if (dir == 0) return launch_col<1024, -1, true>(c, p, blocks);
-    return dir < 0 ? launch_col<1024, -1, false>(c, p, blocks) : launch_col<1024, 1, false>(c, p, blocks);
+    return with_grid(c->g.G, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        if (dir == 0) return p.soft != 0.0f ? launch_col<N, -1, true, 3>(c, p, blocks) : launch_col<N, -1, true>(c, p, blocks);
+        return dir < 0 ? launch_col<N, -1, false>(c, p, blocks) : launch_col<N, 1, false>(c, p, blocks);
+    });
 }
 
 // sb: the interleaving of `spec` (0 for the plane buffers of a slab)
 hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int64_t rows, int sb)
 {
     const int blocks = (int)(rows / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
-    if (c->g.G == 512) {
-        if (forward) k_row_r2c<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle, sb);
-        else k_row_c2r<512><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle, sb);
-    } else {
-        if (forward) k_row_r2c<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle, sb);
-        else k_row_c2r<1024><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle, sb);
-    }
-    return hipGetLastError();
+    return with_grid(c->g.G, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        if (forward) k_row_r2c<N><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle, sb);
+        else k_row_c2r<N><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle, sb);
+        return hipGetLastError();
+    });
 }
 
 }  // namespace
 
-bool pm_fft_custom_supported(int G) { return G == 512 || G == 1024; }
+bool pm_fft_custom_supported(int G) { return G == 128 || G == 256 || G == 512 || G == 1024; }
 
 // log2 of the planes whose rows the whole-mesh half spectrum interleaves (pm_spec_row).  At N = 1024 a third of the
 // address translations of the pass along i miss the CU's TLB in plain order (1024 rows, 4.3 MB apart, per tile); four
@@ -459,8 +472,10 @@ hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *bl
     while ((1 << p.gs_shift) < planes) ++p.gs_shift;
     p.block_stride = (int64_t)planes * planes * P;
     const int nb = planes * p.tiles;
-    if (G == 512) return dir < 0 ? launch_col<512, -1, false, 1>(c, p, nb) : launch_col<512, 1, false, 2>(c, p, nb);
-    return dir < 0 ? launch_col<1024, -1, false, 1>(c, p, nb) : launch_col<1024, 1, false, 2>(c, p, nb);
+    return with_grid(G, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        return dir < 0 ? launch_col<N, -1, false, 1>(c, p, nb) : launch_col<N, 1, false, 2>(c, p, nb);
+    });
 }
 
 // spec_t: (G, ny, Ghp), transform axis first; its rows are mesh rows y0 .. y0 + ny - 1

@@ -89,7 +89,8 @@ template <int DIR> __device__ __forceinline__ void fft16(float2 *v)
 
 template <int R, int DIR> __device__ __forceinline__ void fft_r(float2 *v)
 {
-    if constexpr (R == 4) fft4<DIR>(v);
+    if constexpr (R == 2) { const float2 a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b); }
+    else if constexpr (R == 4) fft4<DIR>(v);
     else if constexpr (R == 8) fft8<DIR>(v);
     else fft16<DIR>(v);
 }
@@ -104,14 +105,38 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// 64-point FFT of one value per lane: radix 2, six Stockham stages through the wave's LDS buffer.  A stage has 32
+// butterflies; both halves of the wave work each of them out and each half writes one of its two results.
+template <int DIR>
+__device__ __forceinline__ void wave_fft64(float2 &v, float2 *buf, const float2 *tw, int j)
+{
+    const int b = j & 31;
+    const bool upper = j >= 32;
+    wave_sync();
+    buf[j] = v;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int Ns = 1 << s, k = b & (Ns - 1);
+        wave_sync();
+        const float2 x0 = buf[b];
+        const float2 x1 = cmul(buf[b + 32], twid<DIR>(tw[k * (64 >> s)]));          // exp(-+ 2 pi i k / (2 Ns)) from the table of 128
+        const float2 y = upper ? csub(x0, x1) : cadd(x0, x1);
+        wave_sync();
+        buf[((b - k) << 1) + k + (upper ? Ns : 0)] = y;
+    }
+    wave_sync();
+    v = buf[j];
+}
+
 // M-point FFT, M = 64 E, of the values a wave holds as v[r] = element (lane + 64 r), r < E; result in
 // the same form.  `buf` is the wave's own M-element LDS exchange buffer, `tw` the table
-// exp(-2 pi i q / (2 M)) in LDS, j the lane.  Radix-E Stockham (E = 4: four stages, E = 8: three):
-// one butterfly per lane per stage, every stage reads elements j + 64 r.
+// exp(-2 pi i q / (2 M)) in LDS, j the lane.  Radix-E Stockham (E = 2: seven stages, E = 4: four, E = 8: three):
+// one butterfly per lane per stage, every stage reads elements j + 64 r.  E = 1 is the 64-point transform above.
 template <int E, int DIR>
 __device__ __forceinline__ void wave_fft(float2 *v, float2 *buf, const float2 *tw, int j)
 {
-    constexpr int LOG = E == 4 ? 2 : 3, STAGES = E == 4 ? 4 : 3;
+    if constexpr (E == 1) { wave_fft64<DIR>(v[0], buf, tw, j); return; }
+    constexpr int LOG = E == 2 ? 1 : E == 4 ? 2 : 3, STAGES = E == 2 ? 7 : E == 4 ? 4 : 3;
     fft_r<E, DIR>(v);                                   // stage 1, Ns = 1: no twiddles
     wave_sync();
 #pragma unroll

@@ -1094,7 +1094,13 @@ static hipError_t deposit_dispatch(pm_ctx *c)
 hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum)
 {
     if (!to_spectrum) return deposit_dispatch<0>(c);
-    return c->g.G == 512 ? deposit_dispatch<512>(c) : deposit_dispatch<1024>(c);
+    switch (c->g.G) {
+    case 128: return deposit_dispatch<128>(c);
+    case 256: return deposit_dispatch<256>(c);
+    case 512: return deposit_dispatch<512>(c);
+    case 1024: return deposit_dispatch<1024>(c);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <typename TP, typename TV>

@@ -333,6 +333,42 @@ def test_poisson_512_column_fft(pm):
             assert np.abs(sim.potential() - want).max() <= 2e-5 * np.abs(want).max(), (ax, m)
 
 
+@pytest.mark.parametrize("G", [128, 256])
+def test_poisson_small_hand_written_transforms(pm, G):
+    """G = 128 and 256 (column passes 2 x 8 x 8 and 4 x 8 x 8; 64- and 128-point row transforms): the solve against
+    the oracle (scipy's transforms, the reference's own arithmetic) and against the rocFFT-only path; and a fused step
+    (deposit emits z-transformed rows) with the same bits as the staged one."""
+    rng = np.random.default_rng(G)
+    dens = rng.random((G, G, G), dtype=np.float32) ** 6
+    dens[10:14, G - 9:G - 5, 30:34] += 40.0
+    ref = O.compute_potential(dens, G)
+    pots = []
+    for rocfft_only in (False, True):
+        with pm.Simulation(G, 1.0, capacity=1, rocfft_only=rocfft_only) as sim:
+            sim.set_mesh(0, dens)
+            sim.solve_potential()
+            pots.append(sim.potential())
+    scale = np.abs(ref).max()
+    assert np.abs(pots[0] - ref).max() <= 1e-5 * scale and np.abs(pots[1] - ref).max() <= 1e-5 * scale
+    n, L, dt = 300_000, 10000, 0.005
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    pos[: n // 2] = (5000 + rng.normal(0, 150, (n // 2, 3))).astype(np.float32)
+    vel = rng.normal(0, 2000, (n, 3)).astype(np.float32)
+    mass = (rng.random(n) + 0.5).astype(np.float32) * 100
+    out = []
+    for fused in (False, True):
+        with pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused) as sim:
+            sim.step(dt, 3)
+            out.append((sim.positions(), sim.velocities()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    xo, vo = pos, vel
+    for _ in range(3):
+        xo, vo = O.pm_step(xo, vo, mass, G, L, dt)
+    dx = np.abs(out[1][0].astype(np.float64) - xo)
+    assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+    assert np.abs(out[1][1] - vo).max() <= 1e-5 * np.abs(vo).max()
+
+
 def test_poisson_1024_column_fft(pm):
     """G = 1024 (radix 16, 8, 8 columns; 512-point rows): against the rocFFT-only path, which the small-mesh tests pin
     to the oracle, and on single Fourier modes with their analytic answer."""

@@ -27,6 +27,7 @@ def make(n, L, seed, crowd):
 
 
 CASES = {"g32": dict(G=32, L=100, n=20000, dt=0.002, K=5, crowd=0.48),        # rocFFT plans
+         "g128": dict(G=128, L=10000, n=100000, dt=0.0005, K=3, crowd=0.49),    # hand-written transforms, 2 x 8 x 8 columns
          "g512": dict(G=512, L=10000, n=200000, dt=0.0005, K=3, crowd=0.49),    # hand-written transforms
          "g1024": dict(G=1024, L=10000, n=200000, dt=0.0005, K=2, crowd=0.49)}  # ... with 8-column tiles along x
 
@@ -86,7 +87,7 @@ def test_slab_world1_gpu(case, tmp_path):
     check(case, [out])
 
 
-@pytest.mark.parametrize("case,world", [("g32", 2), ("g512", 2), ("g32", 4), ("g512", 4)])
+@pytest.mark.parametrize("case,world", [("g32", 2), ("g128", 2), ("g512", 2), ("g32", 4), ("g512", 4)])
 def test_slab_world_n_one_gpu(case, world, tmp_path):
     """Several processes on the one GPU of the test box, exchanging over gloo: with two the next and the previous rank
     are the same one, with four they differ."""
