@@ -227,6 +227,27 @@ __device__ __forceinline__ void lds_add(double *p, double v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+#ifdef PM_TRACE
+// Tuning builds only (tools/deposit_trace.py): per wave of the deposit kernels the start and the end of its work on
+// the 100 MHz clock, the particles it walked and where it ran.
+constexpr uint32_t TRACE_ROWS = 1u << 19;
+__device__ uint32_t g_trace[2][TRACE_ROWS][4];
+__device__ __forceinline__ void trace_put(int which, uint32_t at, uint64_t t0, uint32_t work)
+{
+    if (lane_id() == 0 && at < TRACE_ROWS) {
+        const uint64_t t1 = wall_clock64();
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_trace[which][at][0] = (uint32_t)t0; g_trace[which][at][1] = (uint32_t)t1; g_trace[which][at][2] = work; g_trace[which][at][3] = hw;
+    }
+}
+#define TRACE_BEGIN const uint64_t trace_t0 = wall_clock64();
+#define TRACE_END(which, at, work) trace_put(which, at, trace_t0, work);
+#else
+#define TRACE_BEGIN
+#define TRACE_END(which, at, work)
+#endif
+
 // The lanes hold (k, lo, hi): cell and the masses for cells k and k+1 (idle lanes: a k no cell
 // has, distinct per lane).  Lanes that share a cell are mostly neighbours (cell order).  Where many
 // neighbours share cells, each stretch of equal k is first summed by a segmented scan over the
@@ -550,6 +571,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
                uint2 *__restrict__ heavy_rows, uint32_t *__restrict__ counters, double *__restrict__ light_rows, pm_geom g)
 {
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then the NFFT twiddles
+    TRACE_BEGIN
     const int G = g.G;
     const uint32_t R = (uint32_t)g.Gd * (uint32_t)G;
     // last rows first: the reorder pass has just written the records of the last rows, and the transform along y that
@@ -598,6 +620,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     if (!in_range) return;
     if (t.longest == 0 && !crowded) {
         emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp, g.sb);
+        TRACE_END(0, row, 0u)
         return;
     }
     uint32_t entry = 0;
@@ -622,6 +645,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     } else {
         emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp, g.sb);
     }
+    TRACE_END(0, row, p.total | (crowded ? 0x80000000u : 0u))
 }
 
 // One wave per unit of a crowded source row: its particles into four LDS rows, written out as 4 G doubles
@@ -637,6 +661,7 @@ k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     const uint32_t units = counters[COUNTER_UNITS];
     const uint32_t waves = gridDim.x * (UNIT_BLOCK / 64);
     for (uint32_t u = blockIdx.x * (UNIT_BLOCK / 64) + (uint32_t)wave_id(); u < units; u += waves) {
+        TRACE_BEGIN
         const uint32_t row = unit_src[u];
         const uint32_t beg = rs[row] + (u - row_unit[row]) * UNIT;
         const uint32_t last = rs[row + 1], end = beg + UNIT < last ? beg + UNIT : last;
@@ -646,6 +671,7 @@ k_deposit_units(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         double *out = unit_rows + (size_t)u * 4 * G;
         for (int c = lane_id(); c < 4 * G; c += 64) out[c] = acc[c];
         pmfft::wave_sync();
+        TRACE_END(1, u, end - beg)
     }
 }
 
@@ -1068,7 +1094,11 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     // The units need the plan only: they are summed on the side stream while the rows are walked on this one --
     // unless recent deposits had no units at all (the count comes back to the host without anyone waiting for
     // it, so it is a step or two old: good enough to decide where to launch a kernel that finds out for itself).
+#ifdef PM_NO_BESIDE
+    const bool beside = false;                          // (tuning builds: each kernel's own duration)
+#else
     const bool beside = *c->units_seen != 0;
+#endif
     hipStream_t us = beside ? c->side : c->stream;
     if (beside) {
         if ((e = hipEventRecord(c->ev_fork, c->stream)) != hipSuccess) return e;
@@ -1229,3 +1259,12 @@ hipError_t pm_launch_outbox_counts(pm_ctx *c, int64_t *device_counts)
     k_outbox_counts<<<grid_for(c->nslabs + 1), BLOCK, 0, c->stream>>>(c->outbox_count, c->nslabs, device_counts);
     return hipGetLastError();
 }
+
+#ifdef PM_TRACE
+// tuning builds only: copies the wave trace of the last deposit to the host (2 x TRACE_ROWS x 4 words)
+extern "C" int pm_debug_trace(void *host, size_t bytes)
+{
+    if (bytes > sizeof(g_trace)) bytes = sizeof(g_trace);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
