@@ -130,16 +130,26 @@ k_digit_offsets(uint32_t *__restrict__ counts)
 
 // ---- where a pass puts a pair --------------------------------------------------------------------------------------
 
-// the sorted pairs, nothing else
+// the sorted pairs, nothing else.  NARROW: fewer than 2^30 pairs of 4-byte keys, so a pair's place times four fits 32
+// bits and a store is the array's address (the same in all lanes) plus a 32-bit offset per lane.
 template <typename K>
 struct pair_sink {
     K *kout; uint32_t *vout;
-    __device__ __forceinline__ void operator()(const uint32_t (&dest)[SORT_ITEMS], const K (&key)[SORT_ITEMS], const uint32_t (&val)[SORT_ITEMS],
-                                               const bool (&live)[SORT_ITEMS]) const
+    template <bool NARROW>
+    __device__ __forceinline__ void put(const uint32_t (&dest)[SORT_ITEMS], const K (&key)[SORT_ITEMS], const uint32_t (&val)[SORT_ITEMS],
+                                        const bool (&live)[SORT_ITEMS]) const
     {
 #pragma unroll
-        for (int i = 0; i < SORT_ITEMS; ++i)
-            if (live[i]) { kout[dest[i]] = key[i]; vout[dest[i]] = val[i]; }
+        for (int i = 0; i < SORT_ITEMS; ++i) {
+            if (!live[i]) continue;
+            if constexpr (NARROW && sizeof(K) == 4) {
+                const uint32_t off = dest[i] << 2;
+                *(K *)((char *)kout + off) = key[i];
+                *(uint32_t *)((char *)vout + off) = val[i];
+            } else {
+                kout[dest[i]] = key[i]; vout[dest[i]] = val[i];
+            }
+        }
     }
 };
 
@@ -186,6 +196,7 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
     uint32_t *gdelta = dstart + SIZE;                   // place in the output minus place in the tile, per digit
     uint32_t *misc = gdelta + SIZE;                     // [0] the tile, [1..] scan scratch
     const int t = threadIdx.x, lane = lane_id(), w = wave_id();
+    (void)lane;
 
     if (t == 0) misc[0] = atomicAdd(ticket, 1u);
     for (uint32_t q = t; q < SORT_WAVES * SIZE; q += SORT_BLOCK) whist[q] = 0u;
@@ -198,32 +209,40 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
 
     K key[SORT_ITEMS];
     uint32_t val[SORT_ITEMS], pos[SORT_ITEMS];
+    const K *ktile = kin + base;                        // (a uniform base and a small index: no 64-bit address per lane)
+    const uint32_t *vtile = COUNTED ? nullptr : vin + base;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const uint32_t q = first + 64u * i;
         const bool live = q < count;
-        key[i] = live ? kin[base + q] : (K)0;
+        key[i] = live ? ktile[q] : (K)0;
         // COUNTED: the values that go in are the storage indices 0, 1, 2, ... -- nothing to read
-        val[i] = COUNTED ? base + q : (live ? vin[base + q] : 0u);
+        val[i] = COUNTED ? base + q : (live ? vtile[q] : 0u);
     }
 
+    // Rank of every pair among the pairs of its wave with the same digit.  The lanes whose digits agree find each
+    // other one digit bit at a time: `mine` is the bit spread over a word, `set` the lanes that have it, and a lane
+    // keeps the lanes that agree with it -- peers & ~(set ^ mine), one three-input bit operation per half of the wave.
     uint32_t *wh = whist + (size_t)w * SIZE;
-    const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const bool live = first + 64u * i < count;
         const uint32_t d = digit_of(key[i], bit, mask);
-        unsigned long long peers = __ballot(live);
+        const unsigned long long all = __ballot(live);
+        uint32_t plo = (uint32_t)all, phi = (uint32_t)(all >> 32);
 #pragma unroll
         for (unsigned b = 0; b < RADIX; ++b) {
-            const bool one = (d >> b) & 1u;
-            const unsigned long long set = __ballot(one);
-            peers &= one ? set : ~set;
+            int32_t mine;                               // 0 or -1 (one instruction; the compiler spells a builtin as two shifts)
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mine) : "v"(d), "n"(b));
+            const unsigned long long set = __ballot(mine != 0);
+            plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)set, (uint32_t)mine, 0x90);
+            phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(set >> 32), (uint32_t)mine, 0x90);
         }
         if (live) {
             const uint32_t seen = wh[d];                // every lane of the group reads the count ...
-            pos[i] = seen + (uint32_t)__popcll(peers & below);
-            if ((peers & below) == 0ull) wh[d] = seen + (uint32_t)__popcll(peers);      // ... before its first lane raises it
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));     // peers in lower lanes
+            pos[i] = seen + before;
+            if (before == 0u) wh[d] = seen + (uint32_t)__popc(plo) + (uint32_t)__popc(phi);      // ... before its first lane raises it
         }
     }
     __syncthreads();
@@ -287,7 +306,7 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
         val[i] = live[i] ? svals[q] : 0u;
         dest[i] = gdelta[digit_of(key[i], bit, mask)] + q;
     }
-    sink(dest, key, val, live);
+    sink.template put<sizeof(S) == 4>(dest, key, val, live);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
