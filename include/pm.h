@@ -93,6 +93,24 @@ int pm_set_particles(pm_ctx *ctx, const void *pos, int pos_dtype, const void *ve
 enum { PM_IC_UNIFORM = 0, PM_IC_TWO_GALAXY = 1, PM_IC_DISK = 2 };
 int pm_generate(pm_ctx *ctx, int kind, int64_t n, uint64_t seed, const double *params, int nparams);
 
+/* generate_ellipse_importance(N_particles, a, b, c, M_tot, seed) and generate_diffuse_sphere_importance(N_particles, R,
+ * M_tot, seed): galaxy_generation_functions.py:181-244 (with virial_ellipsoid, :9-94) and :267-383, computed on the
+ * device in float64 -- importance weights normalised to the total mass, enclosed mass over the particles sorted by
+ * radius, circular speeds, tangential directions.  No context: the call allocates what it needs on `device` and
+ * frees it.  positions (n,3), velocities (n,3), masses (n): host arrays of doubles, written in the particles' order
+ * (PM_GALAXY_DIFFUSE_SPHERE: the first int(0.5 n) are the stars, label "1", the rest dark matter, label "2").
+ *   PM_GALAXY_ELLIPSE          params: a, b, c, M_tot, disp (the reference's default dispersion fraction is 0.1)
+ *   PM_GALAXY_DIFFUSE_SPHERE   params: R, M_tot, stellar_fraction (0.25 in the reference), R_dm (390 in the reference)
+ * normals: the standard normal deviates the generator consumes, in the order the reference draws them, or NULL.
+ *   ellipse: (n,3) for the positions, then n and n for the in-plane dispersion (5 n doubles);
+ *   diffuse sphere: (n,3) for the positions, stars first, then (n,3) for the directions (6 n doubles).
+ * With the deviates NumPy's default_rng(seed) hands out, the result is the reference's galaxy for that seed (to the
+ * rounding of sums taken in another order).  NULL: the deviates are drawn on the device (Philox4x32-10, counter =
+ * particle index, key = seed): the same distribution, another stream. */
+enum { PM_GALAXY_ELLIPSE = 0, PM_GALAXY_DIFFUSE_SPHERE = 1 };
+int pm_generate_galaxy(int device, int kind, int64_t n, const double *params, int nparams, uint64_t seed, const double *normals,
+                       double *positions, double *velocities, double *masses);
+
 /* density_func(positions, grid_size, box_size, masses), the CIC branch:
  * functions.py:19-70, call site main.py:50. */
 int pm_deposit(pm_ctx *ctx);

@@ -8,34 +8,16 @@
 // array by array cannot be drawn particle by particle): every particle draws from Philox4x32-10 with its own index as
 // the counter, so a set is a pure function of (kind, n, seed, parameters) whatever the launch shape.
 #include "pm_internal.hpp"
+#include "pm_philox_dev.hpp"
 
 namespace {
 
 constexpr int BLOCK = 256;
 constexpr int MAX_ATTEMPTS = 64;        // rejection loops end here (acceptance is > 95 % per attempt)
 
-struct u32x4 { uint32_t v[4]; };
-
-// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
-__device__ __forceinline__ u32x4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return u32x4{{c0, c1, c2, c3}};
-}
-
-// 32 random bits -> a double strictly inside (0, 1)
-__device__ __forceinline__ double unit(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
-
-struct draw_t {
-    uint32_t lo, hi, k0, k1;
-    __device__ u32x4 operator()(uint32_t purpose, uint32_t attempt) const { return philox(lo, hi, purpose, attempt, k0, k1); }
-};
+using pmrand::u32x4;
+using pmrand::unit;
+using pmrand::draw_t;
 
 // float32 np.remainder(x, L), L > 0: the wrap of main.py:60
 __device__ __forceinline__ float wrap32(float x, float L)

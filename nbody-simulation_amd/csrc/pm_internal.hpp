@@ -158,7 +158,7 @@ struct pm_ctx {
 // the launches of a step.
 struct pm_timer {
     pm_ctx *c; int s; bool on;
-    pm_timer(pm_ctx *c_, int s_) : c(c_), s(s_), on((c_->flags & PM_FLAG_TIMING) != 0)
+    pm_timer(pm_ctx *c_, int s_) : c(c_), s(s_), on(c_ && (c_->flags & PM_FLAG_TIMING) != 0)
     {
         if (!on) return;
         if (c->ev_pending[s] == pm_ctx::RING) read_oldest(c, s);
@@ -219,6 +219,8 @@ hipError_t pm_launch_green_t(pm_ctx *c, float2 *spec_t, int y0, int ny);
 hipError_t pm_launch_transpose_pack(pm_ctx *c, const float2 *spec, float2 *out, bool unpack);
 hipError_t pm_sort_outbox(pm_ctx *c, uint32_t count);
 size_t pm_sort_outbox_tmp_bytes(int64_t cap);
+// 64-bit keys with their indices 0 .. n-1 as values, no context: keys_out sorted, order[r] = where entry r came from
+hipError_t pm_sort_u64(void *tmp, size_t tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, uint32_t *order, size_t n, int device, hipStream_t s);
 hipError_t pm_launch_pack_outbox(pm_ctx *c, uint32_t count, pm_migrant *dst);
 hipError_t pm_launch_outbox_offsets(pm_ctx *c, uint32_t count, uint32_t *offsets);
 hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count);

@@ -16,7 +16,10 @@
 
 namespace {
 
-constexpr int SORT_BLOCK = 1024;                    // threads of a pass's workgroup: 16 waves
+#ifndef PM_SORT_BLOCK
+#define PM_SORT_BLOCK 1024
+#endif
+constexpr int SORT_BLOCK = PM_SORT_BLOCK;           // threads of a pass's workgroup: 16 waves
 constexpr int SORT_WAVES = SORT_BLOCK / 64;
 #ifndef PM_SORT_ITEMS
 #define PM_SORT_ITEMS 8
@@ -471,4 +474,9 @@ hipError_t pm_sort_outbox(pm_ctx *c, uint32_t count)
     while (bits < 64 && ((uint64_t)1 << (bits - 32)) < (uint64_t)c->nslabs) ++bits;
     return sort_dispatch<uint64_t>(c->outbox_tmp, c->outbox_tmp_bytes, c->outbox_key, c->outbox_key2, nullptr, c->outbox_idx2, (size_t)count, bits,
                                    pair_sink<uint64_t>{c->outbox_key2, c->outbox_idx2}, c->device, c->stream, c);
+}
+
+hipError_t pm_sort_u64(void *tmp, size_t tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, uint32_t *order, size_t n, int device, hipStream_t s)
+{
+    return sort_dispatch<uint64_t>(tmp, tmp_bytes, keys_in, keys_out, nullptr, order, n, 64u, pair_sink<uint64_t>{keys_out, order}, device, s, nullptr);
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "pm_destroy": (None, [_c_p]),
     "pm_set_particles": (_int, [_c_p, _c_p, _int, _c_p, _int, _c_p, _i64]),
     "pm_generate": (_int, [_c_p, _int, _i64, ctypes.c_uint64, _c_p, _int]),
+    "pm_generate_galaxy": (_int, [_int, _int, _i64, _c_p, _int, ctypes.c_uint64, _c_p, _c_p, _c_p, _c_p]),
     "pm_deposit": (_int, [_c_p]),
     "pm_potential": (_int, [_c_p]),
     "pm_set_softening": (_int, [_c_p, _dbl]),

@@ -252,6 +252,17 @@ def make_edges():
           int((d["wrap_out"] == np.float32(L)).sum()))
 
 
+def make_virial():
+    """virial_ellipsoid (galaxy_generation_functions.py:9-94) called with a seed on the positions and masses of the
+    committed ellipse file: inside generate_ellipse_importance it is called without one, so that file's velocities
+    cannot be reproduced; this one pins the restatement of the function itself.  Also the equal-mass sphere's
+    recipe is not needed: the diffuse sphere file is reproducible from its seed."""
+    e = np.load(os.path.join(OUT, "galaxy_ellipse_importance_1052_n5000.npz"))
+    v = GGF.virial_ellipsoid(e["positions"], e["masses"], a=3, b=1.8, c=1.5, G=1.0, seed=7)
+    np.savez_compressed(os.path.join(OUT, "galaxy_virial_seed7_n5000.npz"), velocities=v, seed=7, a=3.0, b=1.8, c=1.5)
+    print("virial:", v.shape, float(np.abs(v).max()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["edges", "uniform", "c1mini"]
@@ -263,3 +274,5 @@ if __name__ == "__main__":
         make_c1mini()
     if "ngp" in which:
         make_ngp()
+    if "virial" in which:
+        make_virial()
