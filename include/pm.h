@@ -114,7 +114,12 @@ int pm_generate_galaxy(int device, int kind, int64_t n, const double *params, in
 /* density_func(positions, grid_size, box_size, masses), the CIC branch:
  * functions.py:19-70, call site main.py:50. */
 int pm_deposit(pm_ctx *ctx);
-/* compute_potential(density, grid_size): functions.py:73-89, call site main.py:51. */
+/* compute_potential(density, grid_size): functions.py:73-89, call site main.py:51.
+ * Parity with the reference is by tolerance here, by construction: a real-to-complex transform (hand-written for G =
+ * 128 .. 1024, rocFFT otherwise) stands in for pocketfft's complex one, 1/k^2 is a float32 reciprocal multiply folded
+ * with the 1/G^3 of the inverse transform, and the mean that functions.py:81 subtracts is not subtracted (the k = 0
+ * mode is set to zero either way, functions.py:86): the result agrees within 1e-5 of the largest |potential|, not bit
+ * for bit.  Returns PM_ESTATE when the density mesh does not hold a deposit (see pm_get_mesh). */
 int pm_potential(pm_ctx *ctx);
 /* Optional Gaussian softening of the Poisson solve: the Green's function becomes 1/k^2 * exp(-(sigma k_phys)^2 / 2),
  * i.e. the density is smoothed with a Gaussian of standard deviation `length` (in the units of box_size) before the
@@ -151,6 +156,9 @@ void pm_host_free(void *p);
  * before; *pos_dtype / *vel_dtype report what was written. */
 int pm_get_particles(pm_ctx *ctx, void *pos, int *pos_dtype, void *vel, int *vel_dtype);
 int pm_get_forces(pm_ctx *ctx, float *forces /* (n,3) */);
+/* A mesh can be read (and the stage that consumes it can run) once the stage that writes it has run or pm_set_mesh
+ * has put it there; otherwise PM_ESTATE.  pm_step with PM_FLAG_FUSED_GRADIENT writes no gradient meshes and, on the
+ * hand-written transforms, no density mesh: after it only PM_MESH_POTENTIAL can be read. */
 int pm_get_mesh(pm_ctx *ctx, int which, float *out /* G*G*G */);
 /* Upload a mesh, so that one stage can be run on the caller's input
  * (granular mode: compute_potential(density), np.gradient(potential),

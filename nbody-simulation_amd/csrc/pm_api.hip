@@ -102,6 +102,13 @@ int whole_mesh(pm_ctx *c)
     return PM_OK;
 }
 
+// the float32 mesh `which` must hold the output of the stage before, or what pm_set_mesh put there
+int need_mesh(pm_ctx *c, int which, const char *what)
+{
+    if (c->mesh_valid & (1u << which)) return PM_OK;
+    return fail(c, PM_ESTATE, std::string("no ") + what + ": run the stage that writes it (or pm_set_mesh) first; a fused pm_step keeps neither the density nor the gradient meshes");
+}
+
 int need_particles(pm_ctx *c)
 {
     if (!c) return PM_EINVAL;
@@ -227,7 +234,7 @@ void pm_destroy(pm_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
-    hipFree(c->frac);
+    hipFree(c->frac); hipFree(c->elog);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
     hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
@@ -353,6 +360,8 @@ static int deposit_impl(pm_ctx *c, bool to_spectrum)
     TRY(ensure_binned(c));
     stage_timer t(c, PM_STAGE_DEPOSIT);
     HIP_TRY(c, pm_launch_deposit(c, to_spectrum));
+    if (to_spectrum) c->mesh_valid &= ~(1u << PM_MESH_DENSITY);     // the rows left as half-spectrum rows
+    else c->mesh_valid |= 1u << PM_MESH_DENSITY;
     return PM_OK;
 }
 
@@ -363,7 +372,9 @@ static int potential_impl(pm_ctx *c, bool have_z)
 {
     TRY(whole_mesh(c));
     if (!c) return PM_EINVAL;
+    if (!have_z) TRY(need_mesh(c, PM_MESH_DENSITY, "density"));
     HIP_TRY(c, hipSetDevice(c->device));
+    c->mesh_valid |= 1u << PM_MESH_POTENTIAL;
     if (c->fft_custom && !(c->flags & PM_FLAG_TIMING)) {
         // The three column passes (along y, along x with the Green multiply, back along y) touch the same columns c:
         // they are run over one group of column tiles after the other, a group being small enough (200 MB) that
@@ -438,9 +449,11 @@ int pm_gradient(pm_ctx *c)
 {
     TRY(whole_mesh(c));
     if (!c) return PM_EINVAL;
+    TRY(need_mesh(c, PM_MESH_POTENTIAL, "potential"));
     HIP_TRY(c, hipSetDevice(c->device));
     stage_timer t(c, PM_STAGE_GRADIENT);
     HIP_TRY(c, pm_launch_gradient(c));
+    c->mesh_valid |= (1u << PM_MESH_GX) | (1u << PM_MESH_GY) | (1u << PM_MESH_GZ);
     return PM_OK;
 }
 
@@ -448,6 +461,7 @@ int pm_forces(pm_ctx *c)
 {
     TRY(whole_mesh(c));
     TRY(need_particles(c));
+    for (int w = PM_MESH_GX; w <= PM_MESH_GZ; ++w) TRY(need_mesh(c, w, "gradient"));
     HIP_TRY(c, hipSetDevice(c->device));
     stage_timer t(c, PM_STAGE_GATHER);
     HIP_TRY(c, pm_launch_gather(c, 0.0, false, true, false));
@@ -471,6 +485,7 @@ int pm_gather_kick_drift(pm_ctx *c, double dt)
 {
     TRY(whole_mesh(c));
     TRY(need_particles(c));
+    for (int w = PM_MESH_GX; w <= PM_MESH_GZ; ++w) TRY(need_mesh(c, w, "gradient"));
     HIP_TRY(c, hipSetDevice(c->device));
     return gather_kick_drift(c, dt, false);
 }
@@ -493,6 +508,7 @@ int pm_step(pm_ctx *c, double dt, int nsteps)
         TRY(deposit_impl(c, z_in_deposit));
         TRY(potential_impl(c, z_in_deposit));
         if (!fused) TRY(pm_gradient(c));
+        else c->mesh_valid &= ~((1u << PM_MESH_GX) | (1u << PM_MESH_GY) | (1u << PM_MESH_GZ));     // differenced on the fly
         TRY(gather_kick_drift(c, dt, fused));
     }
     return PM_OK;
@@ -517,8 +533,12 @@ int pm_run(pm_ctx *c, double dt, int nsteps, float *trajectory, int energy_every
             if (!c->snap_done[b]) HIP_TRY(c, hipEventCreateWithFlags(&c->snap_done[b], hipEventDisableTiming));
         }
     }
-    double *elog = nullptr;                 // (nsamples, 2) on the device
-    if (nsamples) HIP_TRY(c, hipMalloc((void **)&elog, (size_t)nsamples * 2 * sizeof(double)));
+    if ((size_t)nsamples > c->elog_cap) {   // (nsamples, 2) on the device: grown when a run samples more than any before it
+        if (c->elog) { hipFree(c->elog); c->elog = nullptr; c->elog_cap = 0; }
+        HIP_TRY(c, hipMalloc((void **)&c->elog, (size_t)nsamples * 2 * sizeof(double)));
+        c->elog_cap = (size_t)nsamples;
+    }
+    double *elog = c->elog;
     int rc = PM_OK;
     for (int s = 0; s < nsteps && rc == PM_OK; ++s) {
         rc = pm_step(c, dt, 1);
@@ -551,7 +571,6 @@ int pm_run(pm_ctx *c, double dt, int nsteps, float *trajectory, int energy_every
         if (e != hipSuccess) rc = fail(c, PM_EHIP, hipGetErrorString(e));
         else for (int k = 0; k < nsamples; ++k) { ke[k] = host[2 * k]; pe[k] = host[2 * k + 1]; }
     }
-    if (elog) hipFree(elog);
     if (rc == PM_OK && e1 != hipSuccess) rc = fail(c, PM_EHIP, hipGetErrorString(e1));
     if (rc == PM_OK && e2 != hipSuccess) rc = fail(c, PM_EHIP, hipGetErrorString(e2));
     return rc;
@@ -624,6 +643,7 @@ int pm_get_mesh(pm_ctx *c, int which, float *out)
     if (c->slab) return fail(c, PM_ESTATE, "a slab context has no whole meshes: use pm_slab_planes");
     float *p = mesh_ptr(c, which);
     if (!p || !out) return fail(c, PM_EINVAL, "bad mesh selector or NULL buffer");
+    TRY(need_mesh(c, which, which == PM_MESH_DENSITY ? "density" : which == PM_MESH_POTENTIAL ? "potential" : "gradient"));
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(out, p, (size_t)c->g.M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -639,6 +659,7 @@ int pm_set_mesh(pm_ctx *c, int which, const float *in)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(p, in, (size_t)c->g.M * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->mesh_valid |= 1u << which;
     return PM_OK;
 }
 
@@ -680,6 +701,7 @@ int pm_forces_ngp(pm_ctx *c)
 {
     TRY(whole_mesh(c));
     TRY(need_particles(c));
+    for (int w = PM_MESH_GX; w <= PM_MESH_GZ; ++w) TRY(need_mesh(c, w, "gradient"));
     HIP_TRY(c, hipSetDevice(c->device));
     stage_timer t(c, PM_STAGE_GATHER);
     HIP_TRY(c, pm_launch_force_ngp(c));

@@ -88,6 +88,9 @@ struct pm_ctx {
     bool have_forces = false;
     bool have_forces64 = false;         // forces64 holds force_NGP of the float64 gradient
     bool keys_fresh = false;    // key_in holds the cell keys of the live positions (written by the last drift)
+    unsigned mesh_valid = 0;    // bit PM_MESH_*: that float32 mesh holds what a stage or pm_set_mesh wrote (a fused step writes neither density nor gradients)
+    double *elog = nullptr;     // pm_run: (samples, 2) energies on the device, kept between calls
+    size_t elog_cap = 0;        // samples it holds
 
     // binning scratch
     uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;

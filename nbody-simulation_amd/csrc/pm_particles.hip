@@ -9,6 +9,7 @@
 #include "pm_fft_dev.hpp"
 
 #include <atomic>
+#include <type_traits>
 #include "pm_cell_dev.hpp"
 
 namespace {
@@ -772,18 +773,22 @@ struct outbox_t { pm_migrant *rec; uint64_t *key; uint32_t *count; uint32_t cap;
 // SLAB: the context owns planes [i0, i0 + Gs) of the mesh; phi holds them with one plane below and two
 // above (plane a of the mesh is plane a - i0 + 1 of the buffer, modulo G), and a particle whose new
 // cell lies in another slab is copied to the outbox and gets the key that sorts it behind the rest.
-template <typename TP, typename TV, bool FUSED, bool SLAB = false>
+// MAPPED: the velocity record of slot r is record vmap[r] of Vin (the records lag one reorder behind)
+template <typename TP, typename TV, bool FUSED, bool SLAB, bool MAPPED>
 __global__ void __launch_bounds__(BLOCK)
 k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, const pm_vrec<TV> *__restrict__ Vin,
          pm_vrec<TV> *__restrict__ Vout, const uint32_t *__restrict__ vmap,
          const float *__restrict__ gx, const float *__restrict__ gy, const float *__restrict__ gz,
          const float *__restrict__ phi, float *__restrict__ forces, uint32_t *__restrict__ key_next, int64_t n, pm_geom g,
-         double dt, bool integrate, outbox_t ob = outbox_t{})
+         double dt, bool integrate, outbox_t ob)
 {
     int64_t r = (int64_t)xcd_block<PM_GATHER_XCD>() * BLOCK + threadIdx.x;
     if (r >= n) return;
     const int G = g.G;
     const pm_prec<TP> p = Pin[r];
+    // the velocity record is asked for now -- its slot first, while the position is on its way -- and is there by the
+    // time the forces are summed: two trips to memory in a row less than asking for it where it is used
+    pm_vrec<TV> v = Vin[MAPPED ? vmap[r] : r];
     cell_t c = locate(p, g);
     if constexpr (SLAB) {
         // A particle whose cell lies in another slab should not be here (pm_slab_inbox was handed a record that belongs
@@ -873,7 +878,6 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     // main.py:58-60
     const float dtf = (float)dt;
     float dvx = fx * dtf, dvy = fy * dtf, dvz = fz * dtf;      // float32 product (weak Python float)
-    pm_vrec<TV> v = Vin[vmap ? vmap[r] : r];
     // velocities += forces*dt : the add runs in the velocities' dtype
     if constexpr (sizeof(TV) == 4) { v.x = v.x + dvx; v.y = v.y + dvy; v.z = v.z + dvz; }
     else { v.x = v.x + (double)dvx; v.y = v.y + (double)dvy; v.z = v.z + (double)dvz; }
@@ -1141,16 +1145,21 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
     const pm_vrec<TV> *vin = V[c->vcur];
     pm_vrec<TV> *vout = c->v_stale ? V[1 - c->vcur] : V[c->vcur];
     const uint32_t *vmap = c->v_stale ? c->src : nullptr;
-    if (c->slab) {
-        if constexpr (sizeof(TP) == 4 && sizeof(TV) == 4) {
-            const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap};
-            k_gather<float, float, true, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces,
-                                                                                    c->key_in, n, c->g, dt, integrate, ob);
-        }
-    } else if (fused)
-        k_gather<TP, TV, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate);
-    else
-        k_gather<TP, TV, false><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate);
+    auto launch = [&](auto mapped) {
+        constexpr bool M = decltype(mapped)::value;
+        if (c->slab) {
+            if constexpr (sizeof(TP) == 4 && sizeof(TV) == 4) {
+                const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap};
+                k_gather<float, float, true, true, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces,
+                                                                                           c->key_in, n, c->g, dt, integrate, ob);
+            }
+        } else if (fused)
+            k_gather<TP, TV, true, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate, outbox_t{});
+        else
+            k_gather<TP, TV, false, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate, outbox_t{});
+    };
+    if (vmap) launch(std::true_type{});
+    else launch(std::false_type{});
 }
 
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient)

@@ -145,6 +145,9 @@ struct pair_sink {
 #pragma unroll
         for (int i = 0; i < SORT_ITEMS; ++i) {
             if (!live[i]) continue;
+#ifdef PM_SORT_NOSTORE
+            if (dest[i] != 0xfffffff0u) continue;       // (tuning: a pass without its stores)
+#endif
             if constexpr (NARROW && sizeof(K) == 4) {
                 const uint32_t off = dest[i] << 2;
                 *(K *)((char *)kout + off) = key[i];
@@ -184,6 +187,10 @@ template <typename K, unsigned RADIX> constexpr size_t pass_lds_bytes()
 #ifndef PM_PASS_WAVES
 #define PM_PASS_WAVES 8
 #endif
+#ifndef PM_SORT_LOOK
+#define PM_SORT_LOOK 4
+#endif
+constexpr uint32_t LOOK = PM_SORT_LOOK;             // states of earlier tiles requested at a time
 template <typename K, typename S, unsigned RADIX, bool COUNTED, class Sink>
 __global__ void __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(PM_PASS_WAVES)))
 k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n, const uint32_t *__restrict__ digit_base,
@@ -267,15 +274,33 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
     const uint32_t before = block_exclusive_sum(total, misc + 1);
     if ((uint32_t)t < SIZE) {
         uint32_t earlier = 0;                           // pairs with this digit in the tiles before this one
+#ifdef PM_SORT_NOCHAIN
+        if (false) {                                    // (tuning: a pass that does not wait for the tiles before it)
+#else
         if (tile > 0) {
+#endif
+            // The states of the LOOK tiles before p are requested together: a request travels to the memory side and
+            // back (the L2 of another XCD may hold the newer value), and a tile that started with many others finds its
+            // nearest finished predecessor many tiles back.  They are then read in order, nearest first; at the first one
+            // that has not counted yet the walk starts again from there.
             uint32_t p = tile - 1;
-            for (;;) {
-                const S s = __hip_atomic_load(states + (size_t)p * SIZE + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned flag = (unsigned)(s >> state_bits<S>::SHIFT);
-                if (flag == 0u) { __builtin_amdgcn_s_sleep(1); continue; }      // that tile has not counted yet
-                earlier += (uint32_t)(s & state_bits<S>::COUNT);
-                if (flag == 2u) break;
-                --p;                                    // tile 0 always publishes a PREFIX: p never passes it
+            for (bool done = false; !done;) {
+                S s[LOOK];
+#pragma unroll
+                for (uint32_t k = 0; k < LOOK; ++k)
+                    s[k] = k <= p ? __hip_atomic_load(states + (size_t)(p - k) * SIZE + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (S)0;
+                uint32_t used = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < LOOK; ++k) {
+                    if (done || used != k) continue;    // (an earlier one of these was not ready, or the walk is over)
+                    const unsigned flag = (unsigned)(s[k] >> state_bits<S>::SHIFT);
+                    if (flag == 0u) continue;           // that tile has not counted yet (k <= p: tile 0 always has a PREFIX)
+                    earlier += (uint32_t)(s[k] & state_bits<S>::COUNT);
+                    used = k + 1;
+                    if (flag == 2u) done = true;
+                }
+                p -= done ? 0u : used;
+                if (used == 0u) __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(states + (size_t)tile * SIZE + t, (S)(state_bits<S>::PREFIX | (S)(earlier + total)), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);

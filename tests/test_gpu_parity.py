@@ -892,6 +892,29 @@ def test_errors(pm):
             sim.forces()                                    # pm_forces not called
 
 
+def test_meshes_a_stage_has_not_written_cannot_be_read(pm):
+    """A fused step keeps neither the density nor the gradient meshes: reading them, or running a stage on them, is an
+    error, not stale data; pm_set_mesh and the granular stages make them readable again."""
+    rng = np.random.default_rng(4)
+    pos = (rng.random((5000, 3)) * 100).astype(np.float32)
+    with pm.Simulation(128, 100.0, pos, fused_gradient=True) as sim:      # hand-written transforms: no density mesh either
+        for stage in (sim.density, sim.potential, sim.potential_gradient, sim.solve_potential, sim.gradient, sim.compute_forces):
+            with pytest.raises(pm.PMError):
+                stage()
+        sim.step(0.01)
+        assert np.isfinite(sim.potential()).all()
+        sim.energies()
+        for stage in (sim.density, sim.potential_gradient, sim.solve_potential, sim.compute_forces):
+            with pytest.raises(pm.PMError):
+                stage()
+        sim.deposit(); sim.solve_potential(); sim.gradient(); sim.compute_forces()
+        assert sim.density().sum() > 0 and len(sim.potential_gradient()) == 3 and sim.forces().shape == (5000, 3)
+    with pm.Simulation(16, 100.0, capacity=4) as sim:
+        sim.set_mesh(0, np.ones((16, 16, 16), np.float32))             # PM_MESH_DENSITY
+        sim.solve_potential()
+        assert sim.potential().shape == (16, 16, 16)
+
+
 # ---- optional softening of the solve (pm_set_softening; the reference has none) -----------------
 
 def _blob_density(G, seed):
