@@ -58,7 +58,7 @@ struct col_pass {
     int64_t block_stride;   // Gs * Gs * pitch
 };
 
-// Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 2, 4, 8, 16 at N = 128, 256, 512, 1024).  A column is
+// Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 2, 4, 8, 16, 32 at N = 128, 256, 512, 1024, 2048).  A column is
 // worked on by TPC = N / EPT threads, each holding EPT of its elements; a block is 16 columns = 16 TPC threads
 // (512 or 1024 threads: more waves per CU overlap one tile's loads with another's butterflies better than the 32
 // elements per thread that the registers would allow).
@@ -79,8 +79,9 @@ struct col_pass {
 #define PM_COLS_GREEN_1024 8
 #endif
 template <int N, int DIR, bool GREEN> struct col_plan {
-    static constexpr int C = (N == 1024 && GREEN) ? PM_COLS_GREEN_1024 : 16;
-    static constexpr int EPT = N != 512 ? 16 : GREEN ? PM_EPT_GREEN : DIR < 0 ? PM_EPT_FWD : PM_EPT_INV;
+    // (N = 2048 = 32 * 8 * 8: 8 columns are what fits the LDS, 128 KiB; a thread holds the 32 rows of a first-stage butterfly)
+    static constexpr int C = N == 2048 ? 8 : (N == 1024 && GREEN) ? PM_COLS_GREEN_1024 : 16;
+    static constexpr int EPT = N == 2048 ? 32 : N != 512 ? 16 : GREEN ? PM_EPT_GREEN : DIR < 0 ? PM_EPT_FWD : PM_EPT_INV;
     static constexpr int R1 = N / 64;                   // first radix
     static constexpr int TPC = N / EPT;                 // threads per column
     static constexpr int THREADS = C * TPC;
@@ -330,6 +331,7 @@ template <typename F> hipError_t with_grid(int G, F f)
     case 256: return f(std::integral_constant<int, 256>{});
     case 512: return f(std::integral_constant<int, 512>{});
     case 1024: return f(std::integral_constant<int, 1024>{});
+    case 2048: return f(std::integral_constant<int, 2048>{});
     default: return hipErrorInvalidValue;
     }
 }
@@ -358,7 +360,7 @@ hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *rea
 
 }  // namespace
 
-bool pm_fft_custom_supported(int G) { return G == 128 || G == 256 || G == 512 || G == 1024; }
+bool pm_fft_custom_supported(int G) { return G == 128 || G == 256 || G == 512 || G == 1024 || G == 2048; }
 
 // log2 of the planes whose rows the whole-mesh half spectrum interleaves (pm_spec_row).  At N = 1024 a third of the
 // address translations of the pass along i miss the CU's TLB in plain order (1024 rows, 4.3 MB apart, per tile); four

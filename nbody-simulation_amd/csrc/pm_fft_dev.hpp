@@ -87,12 +87,52 @@ template <int DIR> __device__ __forceinline__ void fft16(float2 *v)
     }
 }
 
+// 32-point DFT, in place, natural order in and out: 4 columns of 8 (n = c + 4 r), the twiddles w32^(c k1), then 8
+// transforms of 4 (output k = k1 + 8 k2).
+template <int DIR> __device__ __forceinline__ void fft32(float2 *v)
+{
+    PM_FFT_FUSE
+    // cos and sin of 2 pi m / 32, m = 0 .. 21 (the largest c k1 is 3 * 7)
+    constexpr float C32[22] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                               0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f,
+                               -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                               -0.92387953251128675613f, -0.98078528040323044913f, -1.0f, -0.98078528040323044913f, -0.92387953251128675613f,
+                               -0.83146961230254523708f, -0.70710678118654752440f, -0.55557023301960222474f};
+    constexpr float S32[22] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f,
+                               0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f, 1.0f, 0.98078528040323044913f,
+                               0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                               0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                               -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f};
+    float2 t[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[c][r] = v[c + 4 * r];
+        fft8<DIR>(t[c]);
+    }
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) {
+            const int m = c * k1;                       // w32^m = exp(DIR * 2 pi i m / 32)
+            t[c][k1] = cmul(t[c][k1], make_float2(C32[m], DIR < 0 ? -S32[m] : S32[m]));
+        }
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) {
+        float2 u[4] = {t[0][k1], t[1][k1], t[2][k1], t[3][k1]};
+        fft4<DIR>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) v[k1 + 8 * k2] = u[k2];
+    }
+}
+
 template <int R, int DIR> __device__ __forceinline__ void fft_r(float2 *v)
 {
     if constexpr (R == 2) { const float2 a = v[0], b = v[1]; v[0] = cadd(a, b); v[1] = csub(a, b); }
     else if constexpr (R == 4) fft4<DIR>(v);
     else if constexpr (R == 8) fft8<DIR>(v);
-    else fft16<DIR>(v);
+    else if constexpr (R == 16) fft16<DIR>(v);
+    else fft32<DIR>(v);
 }
 
 // Orders the LDS accesses of one wave: what its lanes wrote before is visible to all its lanes
@@ -132,10 +172,49 @@ __device__ __forceinline__ void wave_fft64(float2 &v, float2 *buf, const float2 
 // the same form.  `buf` is the wave's own M-element LDS exchange buffer, `tw` the table
 // exp(-2 pi i q / (2 M)) in LDS, j the lane.  Radix-E Stockham (E = 2: seven stages, E = 4: four, E = 8: three):
 // one butterfly per lane per stage, every stage reads elements j + 64 r.  E = 1 is the 64-point transform above.
+// 1024-point FFT of the values a wave holds as v[r] = element (lane + 64 r), r < 16: radix 16, 16, 4.  The first two
+// stages are one butterfly per lane as below; the last has 256 butterflies of 4, four per lane: butterfly b = lane + 64 q
+// reads elements b + 256 r and leaves element b + 256 r of the transform, i.e. v[q + 4 r].
+template <int DIR>
+__device__ __forceinline__ void wave_fft1024(float2 *v, float2 *buf, const float2 *tw, int j)
+{
+    fft16<DIR>(v);                                      // stage 1, Ns = 1
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[16 * j + r] = v[r];
+    {
+        const int k = j & 15;                           // stage 2, Ns = 16: twiddles exp(-+ 2 pi i r k / 256) from the table of 2048
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = buf[j + 64 * r];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], twid<DIR>(tw[8 * r * k]));
+        fft16<DIR>(v);
+        wave_sync();
+        const int j0 = ((j >> 4) << 8) + k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[j0 + 16 * r] = v[r];
+    }
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                       // stage 3, Ns = 256: twiddles exp(-+ 2 pi i r b / 1024)
+        const int b = j + 64 * q;
+        float2 u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = buf[b + 256 * r];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], twid<DIR>(tw[2 * r * b]));
+        fft4<DIR>(u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q + 4 * r] = u[r];
+    }
+}
+
 template <int E, int DIR>
 __device__ __forceinline__ void wave_fft(float2 *v, float2 *buf, const float2 *tw, int j)
 {
     if constexpr (E == 1) { wave_fft64<DIR>(v[0], buf, tw, j); return; }
+    if constexpr (E == 16) { wave_fft1024<DIR>(v, buf, tw, j); return; }
     constexpr int LOG = E == 2 ? 1 : E == 4 ? 2 : 3, STAGES = E == 2 ? 7 : E == 4 ? 4 : 3;
     fft_r<E, DIR>(v);                                   // stage 1, Ns = 1: no twiddles
     wave_sync();

@@ -1095,6 +1095,15 @@ static hipError_t deposit_dispatch(pm_ctx *c)
             allowed.fetch_or(bit, std::memory_order_release);
         }
     }
+    if (lds_rows + tw_bytes > 64 * 1024) {
+        static std::atomic<uint64_t> allowed_rows{0};
+        const uint64_t bit = 1ull << (c->device & 63);
+        if (!(allowed_rows.load(std::memory_order_acquire) & bit)) {
+            e = hipFuncSetAttribute((const void *)k_deposit_rows<NFFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
+            if (e != hipSuccess) return e;
+            allowed_rows.fetch_or(bit, std::memory_order_release);
+        }
+    }
     // The units need the plan only: they are summed on the side stream while the rows are walked on this one --
     // unless recent deposits had no units at all (the count comes back to the host without anyone waiting for
     // it, so it is a step or two old: good enough to decide where to launch a kernel that finds out for itself).
@@ -1133,6 +1142,7 @@ hipError_t pm_launch_deposit(pm_ctx *c, bool to_spectrum)
     case 256: return deposit_dispatch<256>(c);
     case 512: return deposit_dispatch<512>(c);
     case 1024: return deposit_dispatch<1024>(c);
+    case 2048: return deposit_dispatch<2048>(c);
     default: return hipErrorInvalidValue;
     }
 }

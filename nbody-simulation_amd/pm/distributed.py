@@ -35,7 +35,7 @@ def slab_of(positions, grid_size, box_size, world):
 class HipSlabEngine:
     """Local stages of one slab on one GPU through libpm.so."""
 
-    def __init__(self, grid_size, box_size, plane0, nplanes, capacity, device_index=0):
+    def __init__(self, grid_size, box_size, plane0, nplanes, capacity, device_index=0, rocfft_only=False):
         self.lib = _lib.load()
         self.G, self.L, self.i0, self.Gs = int(grid_size), float(box_size), int(plane0), int(nplanes)
         self.world = self.G // self.Gs
@@ -44,7 +44,8 @@ class HipSlabEngine:
         self.cap = int(capacity)
         # FLAG_FUSED_GRADIENT on a slab: where the hand-written transforms apply, the deposit writes its planes already
         # transformed along z (no density mesh); elsewhere the flag changes nothing
-        self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, _lib.FLAG_FUSED_GRADIENT, self.i0, self.Gs)
+        flags = _lib.FLAG_FUSED_GRADIENT | (_lib.FLAG_ROCFFT_ONLY if rocfft_only else 0)
+        self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, flags, self.i0, self.Gs)
         if not self.ctx:
             raise _lib.PMError("pm_create_slab failed: " + (self.lib.pm_last_error(None) or b"?").decode())
         # the library works on torch's current stream: its kernels, torch's copies and the collectives order themselves

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Local phases of ONE slab of a P-way decomposition on one GPU, exchanges left out: what one GPU of the 8-GPU
+configuration (uniform, 2^29 particles, 2048^3 mesh: 256 planes and 2^26 particles per GPU) spends between its
+collectives.  The all-to-alls are replaced by nothing (the slab solves along x on its own blocks: wrong physics, the
+right kernels, sizes and traffic), the halo planes by the slab's own planes.
+
+    python tools/slab_local_phases.py --grid 2048 --slabs 8 --n 67108864 --steps 3
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "nbody-simulation_amd")):
+    sys.path.insert(0, p)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--grid", type=int, default=2048)
+ap.add_argument("--slabs", type=int, default=8)
+ap.add_argument("--n", type=int, default=1 << 26, help="particles in this slab")
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--rocfft-only", action="store_true")
+args = ap.parse_args()
+
+import torch  # noqa: E402
+from pm import _lib  # noqa: E402
+from pm.distributed import HipSlabEngine  # noqa: E402
+
+G, P, L, dt = args.grid, args.slabs, 10000.0, 0.005
+Gs = G // P
+rng = np.random.default_rng(7)
+n = args.n
+pos = np.empty((n, 3), np.float32)
+pos[:, 0] = (rng.random(n) * (L / P) * 0.998 + 0.001 * L / P).astype(np.float32)
+pos[:, 1:] = (rng.random((n, 2)) * L).astype(np.float32)
+vel = np.zeros((n, 3), np.float32)
+mass = np.ones(n, np.float32)
+ids = np.arange(n, dtype=np.uint32)
+e = HipSlabEngine(G, L, 0, Gs, int(n * 1.1) + 4096, 0, rocfft_only=args.rocfft_only)
+e.set_particles(pos, vel, mass, ids)
+del pos, vel, mass, ids
+PH = ("deposit", "fft_zy", "solve_x", "ifft_yz", "gather_kick_drift", "migration")
+acc = dict.fromkeys(PH, 0.0)
+
+
+def step(record):
+    marks = []
+
+    def mark(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((name, ev))
+    mark("start")
+    e.deposit()
+    ghost = e.ghost_out()
+    e.ghost_in(ghost * 0)
+    mark("deposit")
+    e.fft2(-1)
+    blocks = e.pack()
+    mark("fft_zy")
+    e.solve_x(blocks)           # (P, Gs, Gs, pitch) read as (G, Gs, pitch): this slab's rows of every plane, were they exchanged
+    mark("solve_x")
+    e.unpack(blocks)
+    e.fft2(+1)
+    mark("ifft_yz")
+    e.planes_in(1, 0, e.planes_out(1, Gs, 1))
+    e.planes_in(1, Gs + 1, e.planes_out(1, 1, 2))
+    e.gather_kick_drift(dt)
+    mark("gather_kick_drift")
+    counts = e.outbox_counts().cpu().tolist()
+    e.outbox_records(counts[:P])
+    e.inbox(torch.empty((0, 8), dtype=torch.float32, device="cuda"))
+    mark("migration")
+    torch.cuda.synchronize()
+    if record:
+        for (_, a), (name, b) in zip(marks, marks[1:]):
+            acc[name] += a.elapsed_time(b)
+
+
+step(False)
+for _ in range(args.steps):
+    step(True)
+out = {k: round(v / args.steps, 3) for k, v in acc.items()}
+total = sum(out.values())
+m_local = G * G * Gs
+print(json.dumps({"grid": G, "slabs": P, "planes": Gs, "particles_in_slab": e.n, "hand_written_transforms": bool(e.spectral),
+                  "phases_ms": out, "local_ms_per_step": round(total, 3),
+                  "local_algorithmic_GB": round((64 * n + 80 * m_local) / 1e9, 2),
+                  "local_frac_of_8TBps": round((64 * n + 80 * m_local) / (total * 1e-3) / 8e12, 3)}))
+e.close()
