@@ -199,6 +199,9 @@ def parse_args():
                          "into N slabs -- all-to-all transposes, halo planes and particle migration over RCCL (the default for "
                          "--gpus N > 1; with --gpus 1 it runs the same code as one slab).  replicas: N independent copies of the "
                          "single-GPU run, no collective")
+    ap.add_argument("--transpose-chunks", type=int, default=None,
+                    help="slab runs: groups of planes the two all-to-all transposes are cut into and overlapped with the transforms "
+                         "(default: 2 from a 1024^3 mesh on, else 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="--parallelism slab: torch.distributed backend (gloo stages the exchanges through the host: for "
                          "rehearsing the multi-rank run on a box with fewer GPUs than ranks)")
@@ -401,7 +404,8 @@ def slab_main(args, rank, world, local_rank):
     pos, vel, mass = make_workload(args.workload, n, L, 1052)
     mine = slab_of(pos, G, L, world) == rank
     ids = np.arange(n, dtype=np.uint32)[mine]
-    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids, device_index=local_rank, capacity=int(mine.sum() * 1.3) + (1 << 20))
+    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids, device_index=local_rank, capacity=int(mine.sum() * 1.3) + (1 << 20),
+                         transpose_chunks=args.transpose_chunks)
     n_local = int(mine.sum())
     del pos, vel, mass
 
@@ -440,7 +444,7 @@ def slab_main(args, rank, world, local_rank):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {G // world} planes",
                        "particles_per_slab_at_start": loads, "backend": args.backend if world > 1 else None,
-                       "collective_world_size": world},
+                       "collective_world_size": world, "transpose_chunks": sim.transpose_chunks},
             "phases_ms": phases,
             "roofline": {"bound": "hbm", "kernel": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None, "algorithmic_bytes_per_launch": b_step,

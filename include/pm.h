@@ -250,6 +250,15 @@ int pm_slab_fft2(pm_ctx *ctx, int dir);
  * passes along y are done by pack and unpack themselves, straight into and out of the blocks. */
 int pm_slab_pack(pm_ctx *ctx, void *device_blocks);
 int pm_slab_unpack(pm_ctx *ctx, const void *device_blocks);
+/* The same two steps for owned planes [first, first + count) only, so that a caller can exchange the blocks of some
+ * planes while others are still being transformed: pm_slab_forward_planes = the transforms along z (unless the deposit
+ * has done them) and y of those planes into their part of every block (block p, planes first .. first + count - 1:
+ * count*nplanes*pitch consecutive complex64); pm_slab_inverse_planes = from those parts of the blocks the inverse
+ * transforms along y and z into the potential planes.  Only where the hand-written transforms apply and nplanes is a
+ * power of two (PM_ESTATE otherwise: use the whole-slab calls).  Part of compute_potential (functions.py:73-89), like
+ * pm_slab_fft2. */
+int pm_slab_forward_planes(pm_ctx *ctx, void *device_blocks, int first, int count);
+int pm_slab_inverse_planes(pm_ctx *ctx, const void *device_blocks, int first, int count);
 /* compute_potential, the x part (functions.py:75-89), in place on what the all-to-all delivered:
  * (G, nplanes, pitch) complex64 = rows plane0..plane0+nplanes-1 of every mesh plane. */
 int pm_slab_solve_x(pm_ctx *ctx, void *device_spectrum_t);

@@ -461,19 +461,20 @@ hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes
     return launch_col_any(c, dir < 0 ? -1 : 1, p, planes * p.tiles);
 }
 
-// The pass along y of `planes` planes with the all-to-all buffer on one side: forward from spec into blocks, or inverse
-// from blocks into spec.  planes must be a power of two.
-hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *blocks, int planes)
+// The pass along y of the slab's `planes` planes with the all-to-all buffer on one side: forward from spec into blocks,
+// or inverse from blocks into spec -- for planes [first, first + count) of them.  planes must be a power of two.
+hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *blocks, int planes, int first, int count)
 {
     const int G = c->g.G, P = c->g.Ghp;
-    col_pass p = pass_for(c, spec);
+    col_pass p = pass_for(c, spec + (int64_t)first * G * P);
     plain_strides(p, (int64_t)G * P, P);
     p.row_stride = P;
-    p.blocks = blocks;
     p.gs_shift = 0;
     while ((1 << p.gs_shift) < planes) ++p.gs_shift;
+    p.blocks = blocks + ((int64_t)first << p.gs_shift) * P;     // plane `first`'s rows of block 0
     p.block_stride = (int64_t)planes * planes * P;
-    const int nb = planes * p.tiles;
+    const int nb = count * p.tiles;
+    if (nb == 0) return hipSuccess;
     return with_grid(G, [&](auto n) {
         constexpr int N = decltype(n)::value;
         return dir < 0 ? launch_col<N, -1, false, 1>(c, p, nb) : launch_col<N, 1, false, 2>(c, p, nb);

@@ -216,7 +216,7 @@ hipError_t pm_launch_col_fft(pm_ctx *c, int dir);
 hipError_t pm_launch_row_fft_planes(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int planes);
 hipError_t pm_launch_col_fft_planes(pm_ctx *c, int dir, float2 *spec, int planes);
 hipError_t pm_launch_solve_x(pm_ctx *c, float2 *spec_t, int y0, int ny);
-hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *blocks, int planes);
+hipError_t pm_launch_col_fft_blocks(pm_ctx *c, int dir, float2 *spec, float2 *blocks, int planes, int first, int count);
 hipError_t pm_launch_add(pm_ctx *c, float *mesh, const float *other, int64_t n);
 hipError_t pm_launch_green_t(pm_ctx *c, float2 *spec_t, int y0, int ny);
 hipError_t pm_launch_transpose_pack(pm_ctx *c, const float2 *spec, float2 *out, bool unpack);

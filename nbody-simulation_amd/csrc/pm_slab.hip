@@ -263,7 +263,7 @@ int pm_slab_pack(pm_ctx *c, void *device_blocks)
 {
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->spectrum, (float2 *)device_blocks, c->g.Gs));
+    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->spectrum, (float2 *)device_blocks, c->g.Gs, 0, c->g.Gs));
     else HIP_TRY(c, pm_launch_transpose_pack(c, c->spectrum, (float2 *)device_blocks, false));
     TRY(done(c));
     return PM_OK;
@@ -273,8 +273,45 @@ int pm_slab_unpack(pm_ctx *c, const void *device_blocks)
 {
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs));
+    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs, 0, c->g.Gs));
     else HIP_TRY(c, pm_launch_transpose_pack(c, (const float2 *)device_blocks, c->spectrum, true));
+    return PM_OK;
+}
+
+// The same for owned planes [first, first + count) only, so that the all-to-all of some planes can run beside the
+// transforms of others: forward = transforms along z (unless the deposit did them) and y into those planes' part of the
+// blocks; inverse = from their part of the blocks back along y and z into potential planes 1 + first ....
+static int planes_in_turn(pm_ctx *c, int first, int count)
+{
+    TRY(need_slab(c));
+    if (!(c->fft_custom && c->y_in_exchange))
+        return fail(c, PM_ESTATE, "plane-by-plane transforms need the hand-written transforms and a power-of-two number of planes: use pm_slab_fft2 with pm_slab_pack / pm_slab_unpack");
+    if (first < 0 || count < 0 || first + count > c->g.Gs) return fail(c, PM_EINVAL, "plane range outside the slab");
+    return PM_OK;
+}
+
+int pm_slab_forward_planes(pm_ctx *c, void *device_blocks, int first, int count)
+{
+    TRY(planes_in_turn(c, first, count));
+    if (!device_blocks) return fail(c, PM_EINVAL, "NULL buffer");
+    if (count == 0) return PM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t plane = (size_t)c->g.G * c->g.G, splane = (size_t)c->g.G * c->g.Ghp;
+    if (!spectral_deposit(c)) HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density + first * plane, nullptr, c->spectrum + first * splane, count));
+    HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->spectrum, (float2 *)device_blocks, c->g.Gs, first, count));
+    TRY(done(c));
+    return PM_OK;
+}
+
+int pm_slab_inverse_planes(pm_ctx *c, const void *device_blocks, int first, int count)
+{
+    TRY(planes_in_turn(c, first, count));
+    if (!device_blocks) return fail(c, PM_EINVAL, "NULL buffer");
+    if (count == 0) return PM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t plane = (size_t)c->g.G * c->g.G, splane = (size_t)c->g.G * c->g.Ghp;
+    HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs, first, count));
+    HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, c->potential + (1 + first) * plane, c->spectrum + first * splane, count));
     return PM_OK;
 }
 

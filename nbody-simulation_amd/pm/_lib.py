@@ -69,6 +69,8 @@ SIGNATURES = {
     "pm_slab_outbox_records": (_int, [_c_p, _c_p, _c_p, _i64]),
     "pm_slab_get_particles": (_int, [_c_p, _c_p, _c_p, _c_p]),
     "pm_slab_pitch": (_int, [_c_p]),
+    "pm_slab_forward_planes": (_int, [_c_p, _c_p, _int, _int]),
+    "pm_slab_inverse_planes": (_int, [_c_p, _c_p, _int, _int]),
     "pm_stage_times": (_int, [_c_p, _c_p, _c_p]),
     "pm_kernel_times": (_int, [_c_p, _c_p, _c_p]),
     "pm_set_flags": (_int, [_c_p, ctypes.c_uint]),

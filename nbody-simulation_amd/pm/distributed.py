@@ -9,6 +9,11 @@ has its i in that range.  One step of main.py:50-60 becomes
     inverse FFT along y, z (local)     -> one potential plane from the previous rank, two from the next
     gradient + gather + kick + drift   -> particles whose new cell lies in another slab move there
 
+With `transpose_chunks` = C > 1 the two all-to-alls are cut into C groups of planes: going out, the all-to-all of group c
+(asynchronous, on the collective's own stream) runs while the transforms of group c + 1 do; coming back, all C
+all-to-alls are posted after the solve along x, and the inverse transforms of group c start as soon as its all-to-all
+has arrived, beside the all-to-alls of the groups after it.
+
 The local work is done by an engine: `HipSlabEngine` drives libpm.so (include/pm.h, the pm_slab_* calls)
 on device buffers held as torch tensors; the exchanges are torch.distributed collectives on those tensors
 (backend "nccl" = RCCL over xGMI; with "gloo" the tensors are staged through the host).  An engine is
@@ -133,6 +138,22 @@ class HipSlabEngine:
     def transposed_buffer(self):
         return self._blocks[1]
 
+    def blocks_buffer(self):
+        return self._blocks[0]
+
+    @property
+    def planes_in_turn(self):
+        """Whether forward_planes / inverse_planes work here (hand-written transforms, a power-of-two number of planes)."""
+        return self.lib.pm_slab_forward_planes(self.ctx, self._blocks[0].data_ptr(), 0, 0) == 0
+
+    def forward_planes(self, first, count):
+        """The transforms along z and y of owned planes [first, first + count) into their part of blocks_buffer()."""
+        self._check(self.lib.pm_slab_forward_planes(self.ctx, self._blocks[0].data_ptr(), int(first), int(count)))
+
+    def inverse_planes(self, blocks, first, count):
+        assert blocks.is_contiguous() and blocks.device == self.device
+        self._check(self.lib.pm_slab_inverse_planes(self.ctx, blocks.data_ptr(), int(first), int(count)))
+
     def solve_x(self, spectrum_t):
         assert spectrum_t.is_contiguous() and spectrum_t.device == self.device
         self._sync()
@@ -222,6 +243,23 @@ class _Comm:
         else:
             dist.all_to_all_single(recv, send, group=self.group)
 
+    def all_to_all_parts(self, send, recv, lo, hi):
+        """send, recv: (world, planes, E) tensors.  Rows [lo, hi) of send[p] go to rank p and land in rows [lo, hi) of
+        recv[sender] there.  Over RCCL the exchange is asynchronous: the handle returned must be waited for (wait() makes
+        the current stream wait) before recv is read or send rewritten; None means it is done."""
+        if self.world == 1 and not (self.always and self.on):
+            recv[:, lo:hi].copy_(send[:, lo:hi])
+            return None
+        if self.backend != "nccl":
+            # gloo has no list form and moves host memory: one contiguous buffer each way, staged
+            s = send[:, lo:hi].contiguous().cpu()
+            r = torch.empty_like(s)
+            dist.all_to_all_single(r, s, group=self.group)
+            recv[:, lo:hi].copy_(r)
+            return None
+        return dist.all_to_all([recv[p, lo:hi] for p in range(self.world)], [send[p, lo:hi] for p in range(self.world)],
+                               group=self.group, async_op=True)
+
     def shift(self, to_next, to_prev, from_prev_size, from_next_size):
         """Flat tensors to the next and to the previous rank of the ring; returns what the previous and the next rank
         sent here, (from_prev, from_next).  Point-to-point: two sends and two receives posted as one batch (over RCCL one
@@ -281,7 +319,7 @@ class SlabSimulation:
     numbers in the whole run; `engine` defaults to HipSlabEngine on cuda:`device_index`."""
 
     def __init__(self, grid_size, box_size, positions, velocities, masses, ids, *, group=None, device_index=0, engine=None,
-                 capacity=None, always_collective=False):
+                 capacity=None, always_collective=False, transpose_chunks=None):
         self.comm = _Comm(group, always_collective)
         self.G, self.L = int(grid_size), float(box_size)
         world, rank = self.comm.world, self.comm.rank
@@ -293,6 +331,13 @@ class SlabSimulation:
         self.engine = engine if engine is not None else HipSlabEngine(self.G, self.L, rank * self.Gs, self.Gs, cap, device_index)
         self.engine.set_particles(positions, velocities, masses, ids)
         self.next, self.prev = (rank + 1) % world, (rank - 1) % world
+        # groups of planes the two transposes are cut into (see the module text).  By default two where a transpose is long
+        # against the launches it costs (a 1024^3 mesh and larger), one -- the plain all-to-all -- below that.
+        if transpose_chunks is None:
+            transpose_chunks = 2 if (self.G >= 1024 and world > 1) else 1
+        self.transpose_chunks = max(1, min(int(transpose_chunks), self.Gs))
+        if self.transpose_chunks > 1 and not getattr(self.engine, "planes_in_turn", False):
+            self.transpose_chunks = 1
         # profile = True: _step marks the end of each phase (events on torch's current stream for a GPU engine, whose
         # work and collectives all pass through that stream; the host clock otherwise); phase_times() adds them up
         self.profile = False
@@ -348,23 +393,48 @@ class SlabSimulation:
         e.ghost_in(from_prev)
         mark("density_halo")
         # compute_potential (functions.py:73-89)
-        e.fft2(-1)
-        blocks = e.pack()
-        mark("fft_zy")
-        if world == 1 and not (comm.always and comm.on):
-            spec_t = blocks                         # one slab: the blocks are the transposed spectrum already
+        exchange = world > 1 or (comm.always and comm.on)
+        if self.transpose_chunks > 1 and exchange:
+            C = self.transpose_chunks
+            bounds = [Gs * c // C for c in range(C + 1)]
+            blocks, spec_t = e.blocks_buffer(), e.transposed_buffer()
+            b3, t3 = blocks.view(world, Gs, -1), spec_t.view(world, Gs, -1)
+            pending = []
+            for lo, hi in zip(bounds, bounds[1:]):
+                e.forward_planes(lo, hi - lo)
+                pending.append(comm.all_to_all_parts(b3, t3, lo, hi))   # on its way while the next group is transformed
+            mark("fft_zy")
+            for w in pending:
+                if w is not None:
+                    w.wait()
+            mark("transpose")
+            e.solve_x(spec_t)
+            mark("solve_x")
+            pending = [comm.all_to_all_parts(t3, b3, lo, hi) for lo, hi in zip(bounds, bounds[1:])]
+            mark("transpose_back")
+            for w, lo, hi in zip(pending, bounds, bounds[1:]):
+                if w is not None:
+                    w.wait()
+                e.inverse_planes(blocks, lo, hi - lo)                   # beside the all-to-alls of the groups after it
+            mark("ifft_yz")
         else:
-            spec_t = e.transposed_buffer()
-            comm.all_to_all_equal(blocks.reshape(-1), spec_t.reshape(-1))
-        mark("transpose")
-        e.solve_x(spec_t)
-        mark("solve_x")
-        if spec_t is not blocks:
-            comm.all_to_all_equal(spec_t.reshape(-1), blocks.reshape(-1))
-        mark("transpose_back")
-        e.unpack(blocks)
-        e.fft2(+1)
-        mark("ifft_yz")
+            e.fft2(-1)
+            blocks = e.pack()
+            mark("fft_zy")
+            if not exchange:
+                spec_t = blocks                         # one slab: the blocks are the transposed spectrum already
+            else:
+                spec_t = e.transposed_buffer()
+                comm.all_to_all_equal(blocks.reshape(-1), spec_t.reshape(-1))
+            mark("transpose")
+            e.solve_x(spec_t)
+            mark("solve_x")
+            if spec_t is not blocks:
+                comm.all_to_all_equal(spec_t.reshape(-1), blocks.reshape(-1))
+            mark("transpose_back")
+            e.unpack(blocks)
+            e.fft2(+1)
+            mark("ifft_yz")
         # potential planes beside the slab: one below (from the previous rank), two above (from the next rank)
         to_next = e.planes_out(1, Gs, 1)            # my last owned plane
         to_prev = e.planes_out(1, 1, 2)             # my first two owned planes

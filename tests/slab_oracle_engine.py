@@ -96,6 +96,27 @@ class OracleSlabEngine:
     def transposed_buffer(self):
         return self._t
 
+    # the transposes in groups of planes (pm_slab_forward_planes / pm_slab_inverse_planes)
+    planes_in_turn = True
+
+    def blocks_buffer(self):
+        if not hasattr(self, "_b"):
+            self._b = torch.zeros((self.G * self.Gs * self.pitch, 2), dtype=torch.float32)
+        return self._b
+
+    def forward_planes(self, first, count):
+        Gs, w = self.Gs, self.world
+        b = self.blocks_buffer().numpy().reshape(-1).view(np.complex64).reshape(w, Gs, Gs, self.pitch)
+        spec = sfft.rfft2(self.density[first:first + count], axes=(1, 2)).astype(np.complex64)      # (count, G, pitch)
+        for p in range(w):
+            b[p, first:first + count] = spec[:, p * Gs:(p + 1) * Gs, :]
+
+    def inverse_planes(self, blocks, first, count):
+        Gs, w = self.Gs, self.world
+        b = blocks.numpy().reshape(-1).view(np.complex64).reshape(w, Gs, Gs, self.pitch)
+        spec = np.concatenate([b[p, first:first + count] for p in range(w)], axis=1)                # (count, G, pitch)
+        self.potential[1 + first:1 + first + count] = sfft.irfft2(spec, s=(self.G, self.G), axes=(1, 2)).astype(np.float32)
+
     def solve_x(self, spectrum_t):
         G, Gs = self.G, self.Gs
         a = spectrum_t.numpy().reshape(-1).view(np.complex64).reshape(G, Gs, self.pitch)

@@ -42,7 +42,7 @@ def single_context(case, softening=0.0):
         return sim.positions(), sim.velocities()
 
 
-def run_rank(rank, world, port, case, out, softening=0.0):
+def run_rank(rank, world, port, case, out, softening=0.0, chunks=None):
     import torch.distributed as dist
     from pm.distributed import SlabSimulation, slab_of
     c = CASES[case]
@@ -51,7 +51,10 @@ def run_rank(rank, world, port, case, out, softening=0.0):
     pos, vel, mass = make(c["n"], c["L"], 3, c["crowd"])
     mine = slab_of(pos, c["G"], c["L"], world) == rank
     ids = np.arange(c["n"], dtype=np.uint32)
-    with SlabSimulation(c["G"], c["L"], pos[mine], vel[mine], mass[mine], ids[mine], device_index=0, capacity=c["n"]) as sim:
+    with SlabSimulation(c["G"], c["L"], pos[mine], vel[mine], mass[mine], ids[mine], device_index=0, capacity=c["n"],
+                        transpose_chunks=chunks) as sim:
+        if chunks:
+            assert sim.transpose_chunks == (chunks if sim.engine.planes_in_turn else 1)
         start = set(sim.particles()[0].tolist())
         sim.engine.set_softening(softening)
         sim.step(c["dt"], c["K"])
@@ -106,6 +109,25 @@ def test_slab_world_n_one_gpu(case, world, tmp_path):
     assert check(case, outs) > 50
 
 
+@pytest.mark.parametrize("case,world,chunks", [("g512", 2, 2), ("g128", 4, 3), ("g512", 4, 4), ("g32", 2, 2)])
+def test_slab_transposes_in_groups_of_planes(case, world, chunks, tmp_path):
+    """The two transposes cut into groups of planes (pm_slab_forward_planes / pm_slab_inverse_planes between the
+    all-to-alls of the groups; g32 has rocFFT plans, which transform a slab whole, and falls back to one group)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, case, outs[r], 0.0, chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+        assert p.exitcode == 0
+    assert check(case, outs) > 50
+
+
 @pytest.mark.parametrize("case", ["g32", "g512"])
 def test_slab_softened_solve_two_ranks(case, tmp_path):
     """pm_set_softening on slab contexts (the solve along x sees only a range of ky per rank): two processes against the
@@ -129,16 +151,18 @@ def test_slab_softened_solve_two_ranks(case, tmp_path):
     assert np.abs(bare - softened).max() > 2 * 1e-5 * np.abs(bare).max()      # outside what check() tolerates
 
 
-def _rccl_single_rank(port, out):
+def _rccl_single_rank(port, out, case="g32", chunks=None):
     import torch
     import torch.distributed as dist
     from pm.distributed import SlabSimulation
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    c = CASES["g32"]
+    c = CASES[case]
     pos, vel, mass = make(c["n"], c["L"], 3, c["crowd"])
     ids = np.arange(c["n"], dtype=np.uint32)
-    with SlabSimulation(c["G"], c["L"], pos, vel, mass, ids, device_index=0, capacity=c["n"], always_collective=True) as sim:
+    with SlabSimulation(c["G"], c["L"], pos, vel, mass, ids, device_index=0, capacity=c["n"], always_collective=True,
+                        transpose_chunks=chunks) as sim:
+        assert sim.transpose_chunks == (chunks or 1)
         sim.step(c["dt"], c["K"])
         i, x, v = sim.particles()
     np.savez(out, ids=i, pos=x, vel=v, moved=0)
@@ -146,19 +170,21 @@ def _rccl_single_rank(port, out):
     dist.destroy_process_group()
 
 
-def test_slab_collectives_over_rccl_single_rank(tmp_path):
+@pytest.mark.parametrize("case,chunks", [("g32", None), ("g512", 4)])
+def test_slab_collectives_over_rccl_single_rank(tmp_path, case, chunks):
     """Every exchange of the step as a real RCCL collective (backend "nccl"), on the one rank a one-GPU box can hold:
-    device tensors, the host-side particle counts, empty shares.  More ranks need more GPUs."""
+    device tensors, the host-side particle counts, empty shares; with chunks, the transposes as asynchronous all-to-alls
+    of groups of planes beside the transforms of the other groups.  More ranks need more GPUs."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "r0.npz")
-    p = mp.get_context("spawn").Process(target=_rccl_single_rank, args=(port, out))
+    p = mp.get_context("spawn").Process(target=_rccl_single_rank, args=(port, out, case, chunks))
     p.start()
     p.join(200)
     assert p.exitcode == 0
-    check("g32", [out])
+    check(case, [out])
 
 
 def test_slab_errors():

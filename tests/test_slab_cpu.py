@@ -39,7 +39,7 @@ def reference():
     return x, v
 
 
-def run_rank(rank, world, port, out):
+def run_rank(rank, world, port, out, chunks=1):
     from oracle import pm_oracle as O
     O.build()
     from pm.distributed import SlabSimulation, slab_of
@@ -50,7 +50,8 @@ def run_rank(rank, world, port, out):
     mine = slab_of(pos, G, L, world) == rank
     ids = np.arange(N, dtype=np.uint32)
     eng = OracleSlabEngine(G, L, rank * (G // world), G // world)
-    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids[mine], engine=eng)
+    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids[mine], engine=eng, transpose_chunks=chunks)
+    assert sim.transpose_chunks == min(chunks, G // world)
     sim.profile = True                       # marks after every phase must not change anything
     moved = 0
     for _ in range(K):
@@ -90,16 +91,17 @@ def test_slab_world1(tmp_path):
     check([out])
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_slab_world_n_gloo(tmp_path, world):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (4, 1), (2, 3), (4, 2), (4, 4)])
+def test_slab_world_n_gloo(tmp_path, world, chunks):
     """world 2: the next and the previous rank are the same one; world 4: they differ, and a particle can cross two
-    slab faces in the K steps."""
+    slab faces in the K steps.  chunks > 1: the two transposes go in that many groups of planes (of unequal size when
+    the planes of a slab do not divide evenly)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     outs = [str(tmp_path / f"r{r}.npz") for r in range(world)]
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, outs[r])) for r in range(world)]
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, outs[r], chunks)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
