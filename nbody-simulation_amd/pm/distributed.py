@@ -20,6 +20,7 @@ on device buffers held as torch tensors; the exchanges are torch.distributed col
 anything with the methods of HipSlabEngine; the tests drive the same exchange code with a CPU engine.
 """
 import ctypes
+import threading
 import time
 
 import numpy as np
@@ -314,13 +315,82 @@ class _Comm:
             dist.barrier(group=self.group)
 
 
+class ThreadComm:
+    """The exchanges of _Comm between `world` slabs that live in ONE process on one GPU, each driven by a thread of its own:
+    what a rank would send is left where the other threads can see it, and every thread copies its share out on the
+    device.  All threads enqueue on the same stream, so a copy is ordered behind the kernels that produced its source as
+    long as the producer's calls were made first -- which the barrier before every read sees to.  For rehearsing and
+    testing decompositions with more slabs than the box has GPUs (a 2048^3 mesh in eight slabs fits one MI355X); no
+    measurement made this way says anything about links.
+
+        comms = ThreadComm.make(world)
+        threads = [threading.Thread(target=run, args=(comms[r],)) for r in range(world)]      # run builds SlabSimulation(..., comm=comms[r])
+    """
+
+    class _Shared:
+        def __init__(self, world):
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    @classmethod
+    def make(cls, world):
+        shared = cls._Shared(world)
+        return [cls(shared, r, world) for r in range(world)]
+
+    def __init__(self, shared, rank, world):
+        self._s, self.rank, self.world = shared, rank, world
+        self.on, self.always, self.backend, self.group, self.stage_on_host = True, False, "threads", None, False
+
+    def _publish(self, what):
+        self._s.slots[self.rank] = what
+        self._s.barrier.wait()
+
+    def _retire(self):
+        self._s.barrier.wait()          # everybody has read: the slots may be overwritten
+
+    def all_to_all(self, chunks, recv_sizes):
+        self._publish(chunks)
+        got = [self._s.slots[p][self.rank].reshape(-1).clone() for p in range(self.world)]
+        assert [g.numel() for g in got] == [int(x) for x in recv_sizes]
+        self._retire()
+        return got
+
+    def all_to_all_equal(self, send, recv):
+        self._publish(send.view(self.world, -1))
+        r = recv.view(self.world, -1)
+        for p in range(self.world):
+            r[p].copy_(self._s.slots[p][self.rank])
+        self._retire()
+
+    def all_to_all_parts(self, send, recv, lo, hi):
+        self._publish(send)
+        for p in range(self.world):
+            recv[p, lo:hi].copy_(self._s.slots[p][self.rank, lo:hi])
+        self._retire()
+        return None
+
+    def shift(self, to_next, to_prev, from_prev_size, from_next_size):
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        self._publish((to_next.reshape(-1), to_prev.reshape(-1)))
+        from_prev, from_next = self._s.slots[prv][0].clone(), self._s.slots[nxt][1].clone()
+        assert from_prev.numel() == from_prev_size and from_next.numel() == from_next_size
+        self._retire()
+        return from_prev, from_next
+
+    def exchange_counts(self, counts):
+        return torch.cat(self.all_to_all([counts[p:p + 1] for p in range(self.world)], [1] * self.world))
+
+    def barrier(self):
+        self._s.barrier.wait()
+
+
 class SlabSimulation:
     """main.py:50-60 over `world` slabs.  Every rank passes its own particles (see slab_of) and their
     numbers in the whole run; `engine` defaults to HipSlabEngine on cuda:`device_index`."""
 
     def __init__(self, grid_size, box_size, positions, velocities, masses, ids, *, group=None, device_index=0, engine=None,
-                 capacity=None, always_collective=False, transpose_chunks=None):
-        self.comm = _Comm(group, always_collective)
+                 capacity=None, always_collective=False, transpose_chunks=None, comm=None):
+        self.comm = comm if comm is not None else _Comm(group, always_collective)
         self.G, self.L = int(grid_size), float(box_size)
         world, rank = self.comm.world, self.comm.rank
         if self.G % world:

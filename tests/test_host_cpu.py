@@ -169,3 +169,18 @@ def test_oracle_softening_is_a_gaussian_smoothing_of_the_density():
     assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
     assert np.abs(a - O.compute_potential(dens, G)).max() > 0.05 * np.abs(a).max()
     assert np.array_equal(O.compute_potential(dens, G, soft=0.0), O.compute_potential(dens, G))
+
+
+def test_lattice_case_agrees_with_the_oracle():
+    """tests/lattice_case.py (the closed form that the 2048^3 slab test is checked against) against one oracle step."""
+    import lattice_case as LC
+    from oracle import pm_oracle as O
+    G, L, kstride, mode, eps, dt = 32, 10000, 8, 2, 0.5, 0.005
+    v0 = 0.8 * (L / G) / dt
+    scale = LC.scale_for(G, kstride, mode, eps, v0, dt)
+    pos, vel, mass, ids = LC.slab_particles(G, L, kstride, mode, eps, scale, v0, 0, G)
+    x, v = O.pm_step(pos, vel, mass, G, L, dt)
+    want, dv = LC.expected_velocities(ids, G, kstride, mode, eps, scale, v0, dt)
+    assert 0.02 * v0 < dv < 0.1 * v0 and np.abs(v - want).max() <= 1e-4 * dv
+    assert np.abs(want[:, 0] - np.float32(v0)).max() > 0.5 * dv        # the forces are not nothing
+    assert np.array_equal(x, (pos + v * np.float32(dt)) % np.float32(L))

@@ -39,18 +39,18 @@ def reference():
     return x, v
 
 
-def run_rank(rank, world, port, out, chunks=1):
+def run_rank(rank, world, port, out, chunks=1, comm=None):
     from oracle import pm_oracle as O
     O.build()
     from pm.distributed import SlabSimulation, slab_of
     from slab_oracle_engine import OracleSlabEngine
-    if world > 1:
+    if world > 1 and comm is None:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     pos, vel, mass = particles()
     mine = slab_of(pos, G, L, world) == rank
     ids = np.arange(N, dtype=np.uint32)
     eng = OracleSlabEngine(G, L, rank * (G // world), G // world)
-    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids[mine], engine=eng, transpose_chunks=chunks)
+    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids[mine], engine=eng, transpose_chunks=chunks, comm=comm)
     assert sim.transpose_chunks == min(chunks, G // world)
     sim.profile = True                       # marks after every phase must not change anything
     moved = 0
@@ -63,7 +63,7 @@ def run_rank(rank, world, port, out, chunks=1):
     assert sim.phase_times() == dict.fromkeys(sim.PHASES, 0.0)
     i, x, v = sim.particles()
     np.savez(out, ids=i, pos=x, vel=v, moved=moved)
-    if world > 1:
+    if world > 1 and comm is None:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -108,3 +108,30 @@ def test_slab_world_n_gloo(tmp_path, world, chunks):
         p.join(300)
         assert p.exitcode == 0
     assert check(outs) > 50          # particles did cross between the slabs
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 1), (4, 2)])
+def test_slab_world_n_threads(tmp_path, world, chunks):
+    """The same with the slabs as threads of one process exchanging through pm.distributed.ThreadComm."""
+    import threading
+    from pm.distributed import ThreadComm
+    from oracle import pm_oracle as O
+    O.build()
+    comms = ThreadComm.make(world)
+    outs = [str(tmp_path / f"t{r}.npz") for r in range(world)]
+    errors = []
+
+    def run(r):
+        try:
+            run_rank(r, world, 0, outs[r], chunks, comms[r])
+        except BaseException as e:          # a thread that dies must not leave the others at a barrier
+            errors.append(e)
+            comms[r]._s.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    assert check(outs) > 50
