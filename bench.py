@@ -306,15 +306,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    # how steady the number is: the same block of K steps a few more times (the particles keep moving: not the same steps)
-    blocks = [elapsed / args.steps * 1e3] + [timed_block() / args.steps * 1e3 for _ in range(max(args.repeats, 0) if world == 1 else 0)]
-
-    # per-stage and per-kernel durations: HIP events on the engine's stream around the launches, K more steps
+    # per-stage and per-kernel durations: HIP events on the engine's stream around the launches, the K steps that follow
+    # the timed ones (the collision goes on and the particle kernels slow down as the galaxies spread: these steps are
+    # the nearest to the ones timed above)
     sim.set_flags(timing=True, fused_gradient=fused)
     sim.step(DT, args.steps)
     stages = sim.stage_times()
     kernels = sim.kernel_times()
     sim.set_flags(timing=False, fused_gradient=fused)
+
+    # how steady the number is: the same block of K steps a few more times (the particles keep moving: not the same steps)
+    blocks = [elapsed / args.steps * 1e3] + [timed_block() / args.steps * 1e3 for _ in range(max(args.repeats, 0) if world == 1 else 0)]
 
     sim.close()
     # beside the headline: the uniform particle set of the same size on the same mesh (one GPU, default workload only)
