@@ -47,7 +47,12 @@ enum {
                                     row already transformed along z (no density mesh) */
     PM_FLAG_NGP = 8u,         /* pm_create only: pm_step runs the nearest-grid-point branch (CIC_interpolation = False,
                                  main.py:9, 40-41), whose meshes and forces are float64 */
-    PM_FLAG_ROCFFT_ONLY = 4u  /* pm_create only: 3-D rocFFT plans for every grid size (no hand-written column FFT) */
+    PM_FLAG_ROCFFT_ONLY = 4u, /* pm_create only: 3-D rocFFT plans for every grid size (no hand-written column FFT) */
+    PM_FLAG_F64 = 32u         /* pm_create only: pm_step runs the cloud-in-cell branch with every array in float64 -- what
+                                 main.py:50-60 computes when the mesh of functions.py:22, the forces of functions.py:102 and
+                                 the positions after main.py:60 are float64.  The reference has no such switch: this is the
+                                 build mode that is held to 1e-12 against a float64 restatement.  Particles must be given
+                                 as PM_F64 positions and velocities; not tuned */
 };
 
 /* stages reported by pm_stage_times, in this order */
@@ -213,6 +218,13 @@ int pm_gradient_f64(pm_ctx *ctx);
 int pm_forces_ngp_f64(pm_ctx *ctx);
 int pm_get_forces_f64(pm_ctx *ctx, double *forces /* (n,3) */);
 int pm_set_mesh_f64(pm_ctx *ctx, int which, const double *in /* G*G*G */);
+/* The cloud-in-cell calls of the float64 build mode (PM_FLAG_F64 contexts step through pm_deposit_f64 ->
+ * pm_potential_f64 -> pm_gradient_f64 -> these forces with main.py:58-60 in float64 behind them):
+ * pm_deposit_f64: CIC, functions.py:19-70, with a float64 mesh (read with pm_get_mesh_f64(PM_MESH_DENSITY));
+ * pm_forces_f64:  force_CIC, functions.py:99-180, on the float64 gradient with float64 forces (pm_get_forces_f64).
+ * Both need float64 positions and velocities (pm_set_particles with PM_F64, PM_F64), on any context. */
+int pm_deposit_f64(pm_ctx *ctx);
+int pm_forces_f64(pm_ctx *ctx);
 
 /*
  * Slab decomposition of the same path over several GPUs.  The reference is a single-process NumPy

@@ -304,6 +304,8 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     if (!pos && n > 0) return fail(c, PM_EINVAL, "pos is NULL");
     if ((pos_dtype != PM_F32 && pos_dtype != PM_F64) || (vel_dtype != PM_F32 && vel_dtype != PM_F64))
         return fail(c, PM_EINVAL, "dtype must be PM_F32 or PM_F64");
+    if ((c->flags & PM_FLAG_F64) && (pos_dtype != PM_F64 || vel_dtype != PM_F64))
+        return fail(c, PM_EINVAL, "a PM_FLAG_F64 context takes float64 positions and velocities");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pos_in_f64 = c->pos_f64 = (pos_dtype == PM_F64);
@@ -491,6 +493,7 @@ int pm_gather_kick_drift(pm_ctx *c, double dt)
 }
 
 static int step_ngp(pm_ctx *c, double dt);
+static int step_f64(pm_ctx *c, double dt);
 
 int pm_step(pm_ctx *c, double dt, int nsteps)
 {
@@ -499,6 +502,10 @@ int pm_step(pm_ctx *c, double dt, int nsteps)
     if (nsteps < 0) return fail(c, PM_EINVAL, "nsteps < 0");
     if (c->flags & PM_FLAG_NGP) {
         for (int s = 0; s < nsteps; ++s) TRY(step_ngp(c, dt));
+        return PM_OK;
+    }
+    if (c->flags & PM_FLAG_F64) {
+        for (int s = 0; s < nsteps; ++s) TRY(step_f64(c, dt));
         return PM_OK;
     }
     const bool fused = (c->flags & PM_FLAG_FUSED_GRADIENT) != 0;
@@ -686,7 +693,7 @@ int pm_energies(pm_ctx *c, double *ke, double *pe)
     TRY(whole_mesh(c));
     TRY(need_particles(c));
     if (!ke || !pe) return fail(c, PM_EINVAL, "NULL buffer");
-    if ((c->flags & PM_FLAG_NGP) && !c->potential64) return fail(c, PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
+    if ((c->flags & (PM_FLAG_NGP | PM_FLAG_F64)) && !c->potential64) return fail(c, PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
     HIP_TRY(c, hipSetDevice(c->device));
     double *res = c->diag + 2 * 1024;
     HIP_TRY(c, pm_launch_energies(c, res, res + 1));
@@ -860,6 +867,52 @@ int pm_get_forces_f64(pm_ctx *c, double *forces)
     return PM_OK;
 }
 
+// ---- the cloud-in-cell branch in float64 (PM_FLAG_F64) -------------------------------------------------------------
+
+static int need_f64_particles(pm_ctx *c)
+{
+    TRY(whole_mesh(c));
+    TRY(need_particles(c));
+    if (!c->pos_f64 || !c->vel_f64) return fail(c, PM_ESTATE, "the float64 cloud-in-cell calls need float64 positions and velocities (pm_set_particles with PM_F64, PM_F64)");
+    return PM_OK;
+}
+
+// CIC (functions.py:19-70) into a float64 mesh
+int pm_deposit_f64(pm_ctx *c)
+{
+    TRY(need_f64_particles(c));
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(ensure_binned(c));
+    TRY(dalloc(c, &c->density64, (size_t)c->g.M));
+    stage_timer t(c, PM_STAGE_DEPOSIT);
+    HIP_TRY(c, pm_launch_deposit64(c));
+    return PM_OK;
+}
+
+// force_CIC (functions.py:99-180) on the float64 gradient, float64 forces (read with pm_get_forces_f64)
+int pm_forces_f64(pm_ctx *c)
+{
+    TRY(need_f64_particles(c));
+    if (!c->grad64[0]) return fail(c, PM_ESTATE, "no float64 gradient: call pm_gradient_f64 or pm_set_mesh_f64 first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    stage_timer t(c, PM_STAGE_GATHER);
+    HIP_TRY(c, pm_launch_gather64(c, 0.0, false, c->forces64));
+    c->have_forces64 = true;
+    return PM_OK;
+}
+
+// main.py:50-60 with every array in float64
+static int step_f64(pm_ctx *c, double dt)
+{
+    TRY(pm_deposit_f64(c));
+    TRY(pm_potential_f64(c));
+    TRY(pm_gradient_f64(c));
+    stage_timer t(c, PM_STAGE_GATHER);
+    HIP_TRY(c, pm_launch_gather64(c, dt, true, nullptr));
+    c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = true;
+    return PM_OK;
+}
+
 // main.py:50-60 with CIC_interpolation = False
 static int step_ngp(pm_ctx *c, double dt)
 {
@@ -877,7 +930,7 @@ int pm_set_flags(pm_ctx *c, unsigned flags)
 {
     if (!c) return PM_EINVAL;
     if (flags & ~(unsigned)(PM_FLAG_TIMING | PM_FLAG_FUSED_GRADIENT)) return fail(c, PM_EINVAL, "only PM_FLAG_TIMING and PM_FLAG_FUSED_GRADIENT can change");
-    flags |= c->flags & (PM_FLAG_ROCFFT_ONLY | PM_FLAG_NGP);
+    flags |= c->flags & (PM_FLAG_ROCFFT_ONLY | PM_FLAG_NGP | PM_FLAG_F64);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int s = 0; s < pm_ctx::TIMED; ++s) pm_timer::flush(c, s);

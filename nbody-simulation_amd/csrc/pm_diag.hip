@@ -323,7 +323,7 @@ static hipError_t launch_energies(pm_ctx *c, double *partials, double *d_ke, dou
     const pm_prec<double> *pd = c->pos_f64 ? c->pd[u] : nullptr;
     if (c->vel_f64) k_kinetic<double><<<blocks, BLOCK, 0, c->stream>>>(pf, pd, c->vd[c->vcur], vmap, n, part_k);
     else k_kinetic<float><<<blocks, BLOCK, 0, c->stream>>>(pf, pd, c->vf[c->vcur], vmap, n, part_k);
-    if (c->flags & PM_FLAG_NGP) {
+    if (c->flags & (PM_FLAG_NGP | PM_FLAG_F64)) {
         if (c->pos_f64) k_potential_energy<double, double><<<blocks, BLOCK, 0, c->stream>>>(c->pd[u], c->potential64, n, c->g, part_p);
         else k_potential_energy<float, double><<<blocks, BLOCK, 0, c->stream>>>(c->pf[u], c->potential64, n, c->g, part_p);
     } else {
@@ -407,7 +407,7 @@ extern "C" int pm_energies_noalloc(pm_ctx *c, double *device_ke_pe)
     if (!device_ke_pe) return fail(PM_EINVAL, "device_ke_pe is NULL");
     if (c->n > PM_NOALLOC_MAX_PARTICLES)
         return fail(PM_EINVAL, "pm_energies_noalloc takes at most PM_NOALLOC_MAX_PARTICLES (268435456) particles: use pm_energies");
-    if ((c->flags & PM_FLAG_NGP) && !c->potential64)
+    if ((c->flags & (PM_FLAG_NGP | PM_FLAG_F64)) && !c->potential64)
         return fail(PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
     hipError_t e = hipSetDevice(c->device);
     double *partials = nullptr;

@@ -247,3 +247,5 @@ hipError_t pm_launch_ngp_sum(pm_ctx *c);
 hipError_t pm_launch_green64(pm_ctx *c);
 hipError_t pm_launch_gradient64(pm_ctx *c);
 hipError_t pm_launch_ngp_gather(pm_ctx *c, double dt, bool integrate, double *forces);
+hipError_t pm_launch_deposit64(pm_ctx *c);       // cloud-in-cell in float64 (PM_FLAG_F64): density64 from pd[], forces / kick / drift on grad64
+hipError_t pm_launch_gather64(pm_ctx *c, double dt, bool integrate, double *forces);

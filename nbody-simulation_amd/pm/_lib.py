@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PM_LIBRARY") or os.path.join(os.path.dirname(_HERE), 
 
 PM_F32, PM_F64 = 0, 1
 MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ, SLAB_ZSPECTRUM = range(6)
-FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP = 1, 2, 4, 8
+FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP, FLAG_F64 = 1, 2, 4, 8, 32
 IC_KINDS = {"uniform": 0, "two_galaxy": 1, "disk": 2}
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
 KERNELS = ("sort_pass", "reorder", "deposit_rows", "col_y_fwd", "col_x_green", "col_y_inv", "row_inv", "gather")
@@ -53,6 +53,8 @@ SIGNATURES = {
     "pm_potential_f64": (_int, [_c_p]),
     "pm_gradient_f64": (_int, [_c_p]),
     "pm_forces_ngp_f64": (_int, [_c_p]),
+    "pm_deposit_f64": (_int, [_c_p]),
+    "pm_forces_f64": (_int, [_c_p]),
     "pm_get_forces_f64": (_int, [_c_p, _c_p]),
     "pm_create_slab": (_c_p, [_int, _dbl, _i64, _int, ctypes.c_uint, _int, _int]),
     "pm_slab_set_particles": (_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _i64]),

@@ -39,16 +39,23 @@ class Simulation:
     and masses are the bare arrays of main.py:25-33, in their dtypes (float32 or float64)."""
 
     def __init__(self, grid_size, box_size, positions=None, velocities=None, masses=None,
-                 interpolation="CIC", capacity=None, device=0, timing=False, fused_gradient=False, rocfft_only=False):
+                 interpolation="CIC", capacity=None, device=0, timing=False, fused_gradient=False, rocfft_only=False,
+                 float64=False):
+        """float64=True (cloud-in-cell only) makes step / run the float64 build mode (PM_FLAG_F64): mesh, forces,
+        positions and velocities all float64 -- the reference's loop with float64 in place of float32 everywhere."""
         if interpolation not in ("CIC", "NGP"):
             raise ValueError(f"interpolation must be 'CIC' or 'NGP' (main.py:9, 40-41), got {interpolation!r}")
+        if float64 and interpolation != "CIC":
+            raise ValueError("float64=True is the cloud-in-cell branch in float64; the NGP branch is float64 as NumPy runs it")
         self.interpolation = interpolation
+        self.float64 = bool(float64)
         self.lib = L.load()
         self.grid_size, self.box_size = int(grid_size), box_size
         n = 0 if positions is None else len(positions)
         self.capacity = int(capacity if capacity is not None else max(n, 1))
         flags = ((L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
-                 | (L.FLAG_ROCFFT_ONLY if rocfft_only else 0) | (L.FLAG_NGP if interpolation == "NGP" else 0))
+                 | (L.FLAG_ROCFFT_ONLY if rocfft_only else 0) | (L.FLAG_NGP if interpolation == "NGP" else 0)
+                 | (L.FLAG_F64 if float64 else 0))
         self.ctx = self.lib.pm_create(self.grid_size, float(box_size), self.capacity, int(device), flags)
         if not self.ctx:
             raise L.PMError("pm_create failed: " + self.lib.pm_last_error(None).decode())
@@ -79,6 +86,9 @@ class Simulation:
     def set_particles(self, positions, velocities=None, masses=None):
         x = L.as_particle_array(positions, "positions")
         v = None if velocities is None else L.as_particle_array(velocities, "velocities")
+        if self.float64:                # the float64 build mode holds float64 particles
+            x = np.ascontiguousarray(x, np.float64)
+            v = np.zeros_like(x) if v is None else np.ascontiguousarray(v, np.float64)
         m = None if masses is None else np.ascontiguousarray(masses, dtype=np.float32)
         if v is not None and len(v) != len(x) or m is not None and len(m) != len(x):
             raise ValueError("positions, velocities and masses differ in length")
@@ -178,6 +188,13 @@ class Simulation:
 
     def compute_forces_ngp_f64(self):
         self._ck(self.lib.pm_forces_ngp_f64(self.ctx))
+
+    # the cloud-in-cell calls of the float64 build mode (functions.py:19-70 and :99-180 with float64 mesh and forces)
+    def deposit_f64(self):
+        self._ck(self.lib.pm_deposit_f64(self.ctx))
+
+    def compute_forces_f64(self):
+        self._ck(self.lib.pm_forces_f64(self.ctx))
 
     def forces_f64(self):
         f = np.empty((self.n, 3), np.float64)

@@ -167,6 +167,52 @@ def pm_step(positions, velocities, masses, grid_size, box_size, dt, keep=False):
     return x, v
 
 
+# ---- the float64 build mode: main.py:50-60 with float64 in place of float32 everywhere ------------
+# (the reference has no such switch; this is the float64 CPU restatement that the library's PM_FLAG_F64 mode is held
+# to at 1e-12)
+
+def cell_and_fraction_f64(positions, grid_size, box_size):
+    """functions.py:27-43 in float64: cell indices (n,3) int64 and fractions (n,3)."""
+    x = np.remainder(np.asarray(positions, np.float64), float(box_size))
+    s = x * (grid_size / float(box_size))
+    i = s.astype(np.int64)
+    d = s - i
+    i[i >= grid_size] -= grid_size
+    return i, d
+
+
+def force_CIC_f64(potential_gradient, positions, grid_size, box_size):
+    """functions.py:99-180 with float64 gradient meshes and a float64 forces array: the eight corners in the
+    reference's order, w = wx * wy * wz, forces += grad * w."""
+    G = grid_size
+    c, d = cell_and_fraction_f64(positions, G, box_size)
+    c1 = (c + 1) % G
+    w = np.stack((1.0 - d, d))                          # [corner bit, particle, axis]
+    idx = np.stack((c, c1))
+    f = np.zeros((len(c), 3), np.float64)
+    for di, dj, dk in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)):
+        wt = w[di, :, 0] * w[dj, :, 1] * w[dk, :, 2]
+        node = (idx[di, :, 0], idx[dj, :, 1], idx[dk, :, 2])
+        for a in range(3):
+            f[:, a] = f[:, a] + potential_gradient[a][node] * wt
+    return f
+
+
+def pm_step_f64(positions, velocities, masses, grid_size, box_size, dt, keep=False):
+    """One pass of main.py:50-60 with a float64 mesh (functions.py:22), float64 forces (:102) and no cast at main.py:60."""
+    x = np.asarray(positions, np.float64)
+    v = np.asarray(velocities, np.float64)
+    density = CIC_f64(x, grid_size, box_size, masses)
+    potential = compute_potential(density, grid_size)
+    grad = np.gradient(potential)
+    forces = force_CIC_f64(grad, x, grid_size, box_size)
+    v = v + forces * dt
+    x = np.remainder(x + v * dt, float(box_size))
+    if keep:
+        return x, v, dict(density=density, potential=potential, grad=grad, forces=forces)
+    return x, v
+
+
 # ---- secondary variants and diagnostics (numpy restatements) -------------------------------
 
 def NGP(positions, grid_size, box_size, masses):

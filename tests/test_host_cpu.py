@@ -184,3 +184,21 @@ def test_lattice_case_agrees_with_the_oracle():
     assert 0.02 * v0 < dv < 0.1 * v0 and np.abs(v - want).max() <= 1e-4 * dv
     assert np.abs(want[:, 0] - np.float32(v0)).max() > 0.5 * dv        # the forces are not nothing
     assert np.array_equal(x, (pos + v * np.float32(dt)) % np.float32(L))
+
+
+def test_float64_restatement_is_the_float32_one_up_to_float32():
+    """oracle.pm_step_f64 (what the float64 build mode is compared with) against the reference-pinned float32 step."""
+    from oracle import pm_oracle as O
+    rng = np.random.default_rng(3)
+    n, G, L, dt = 5000, 16, 100, 0.01
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    vel = rng.normal(0, 30, (n, 3)).astype(np.float32)
+    mass = (rng.random(n) + 0.5).astype(np.float32)
+    x32, v32, k32 = O.pm_step(pos, vel, mass, G, L, dt, keep=True)
+    x64, v64, k64 = O.pm_step_f64(pos, vel, mass, G, L, dt, keep=True)
+    assert k64["density"].dtype == np.float64 and k64["forces"].dtype == np.float64 and x64.dtype == np.float64
+    assert np.abs(k64["density"] - k32["density"]).max() <= 1e-5 * k32["density"].max()
+    assert np.abs(k64["forces"] - k32["forces"]).max() <= 1e-4 * np.abs(k32["forces"]).max()
+    dx = np.abs(x64 - x32)
+    assert np.minimum(dx, L - dx).max() <= 1e-5 * L and np.abs(v64 - v32).max() <= 1e-5 * np.abs(v32).max()
+    assert abs(k64["density"].sum() - mass.sum(dtype=np.float64)) <= 1e-12 * mass.sum()
