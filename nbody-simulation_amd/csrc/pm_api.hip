@@ -203,6 +203,10 @@ pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int
         fail(nullptr, PM_EHIP, "no such HIP device: " + std::to_string(device) + " of " + std::to_string(ndev));
         return nullptr;
     }
+    if ((flags & PM_FLAG_F64) && ((flags & PM_FLAG_NGP) || slab)) {
+        fail(nullptr, PM_EINVAL, "PM_FLAG_F64 is the cloud-in-cell branch on a whole mesh: not with PM_FLAG_NGP, not on a slab");
+        return nullptr;
+    }
     pm_ctx *c = new pm_ctx;
     c->g.G = grid_size; c->g.Gh = grid_size / 2 + 1;
     c->fft_custom = pm_fft_custom_supported(grid_size) && !(flags & PM_FLAG_ROCFFT_ONLY);
@@ -529,6 +533,8 @@ int pm_run(pm_ctx *c, double dt, int nsteps, float *trajectory, int energy_every
     if (nsteps < 0 || energy_every < 0) return fail(c, PM_EINVAL, "nsteps < 0 or energy_every < 0");
     if (nsteps == 0) return PM_OK;
     if (energy_every > 0 && (!ke || !pe)) return fail(c, PM_EINVAL, "energy_every > 0 needs ke and pe");
+    // (the snapshots are the float32 positions of main.py:60-61; a PM_FLAG_F64 context keeps float64 positions)
+    if (trajectory && (c->flags & PM_FLAG_F64)) return fail(c, PM_ESTATE, "pm_run records float32 trajectories: not on a PM_FLAG_F64 context (step and read the positions instead)");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = (size_t)c->n, snap_bytes = n * 3 * sizeof(float);
     const int nsamples = energy_every > 0 ? (nsteps - 1) / energy_every + 1 : 0;

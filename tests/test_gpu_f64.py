@@ -106,6 +106,12 @@ def test_float64_mode_wants_float64_particles(pm):
     rc = lib.pm_set_particles(ctx, x.ctypes.data, _lib.PM_F32, x.ctypes.data, _lib.PM_F32, None, 4)
     assert rc != 0 and b"float64" in lib.pm_last_error(ctx)
     lib.pm_destroy(ctx)
+    assert not lib.pm_create(16, 100.0, 8, 0, _lib.FLAG_F64 | _lib.FLAG_NGP) and b"PM_FLAG_F64" in lib.pm_last_error(None)
+    with pm.Simulation(16, 100.0, x.astype(np.float64), None, None, float64=True) as sim:
+        with pytest.raises(_lib.PMError):
+            sim.run(2, 0.01, trajectory=True, energy_every=0)      # float32 snapshots: not in this mode
+        traj, en = sim.run(2, 0.01, trajectory=False, energy_every=1)
+        assert traj is None and en.shape == (2, 3)
     # and on an ordinary context the float64 cloud-in-cell calls refuse float32 particles
     with pm.Simulation(16, 100.0, x, x, None) as sim:
         with pytest.raises(_lib.PMError):
