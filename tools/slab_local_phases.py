@@ -23,6 +23,9 @@ ap.add_argument("--slabs", type=int, default=8)
 ap.add_argument("--n", type=int, default=1 << 26, help="particles in this slab")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--rocfft-only", action="store_true")
+ap.add_argument("--workload", default="uniform", help="uniform: --n particles inside slab 0; or a workload of bench.py (two_galaxy, disk): --n is then the WHOLE "
+                                                     "set, and --rank picks the slab whose share is timed (-1: every slab in turn)")
+ap.add_argument("--rank", type=int, default=-1)
 args = ap.parse_args()
 
 import torch  # noqa: E402
@@ -31,63 +34,86 @@ from pm.distributed import HipSlabEngine  # noqa: E402
 
 G, P, L, dt = args.grid, args.slabs, 10000.0, 0.005
 Gs = G // P
-rng = np.random.default_rng(7)
-n = args.n
-pos = np.empty((n, 3), np.float32)
-pos[:, 0] = (rng.random(n) * (L / P) * 0.998 + 0.001 * L / P).astype(np.float32)
-pos[:, 1:] = (rng.random((n, 2)) * L).astype(np.float32)
-vel = np.zeros((n, 3), np.float32)
-mass = np.ones(n, np.float32)
-ids = np.arange(n, dtype=np.uint32)
-e = HipSlabEngine(G, L, 0, Gs, int(n * 1.1) + 4096, 0, rocfft_only=args.rocfft_only)
-e.set_particles(pos, vel, mass, ids)
-del pos, vel, mass, ids
 PH = ("deposit", "fft_zy", "solve_x", "ifft_yz", "gather_kick_drift", "migration")
-acc = dict.fromkeys(PH, 0.0)
 
 
-def step(record):
-    marks = []
+def one_slab(rank, pos, vel, mass, ids):
+    n = len(pos)
+    e = HipSlabEngine(G, L, rank * Gs, Gs, int(n * 1.1) + 4096, 0, rocfft_only=args.rocfft_only)
+    e.set_particles(pos, vel, mass, ids)
+    acc = dict.fromkeys(PH, 0.0)
 
-    def mark(name):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        marks.append((name, ev))
-    mark("start")
-    e.deposit()
-    ghost = e.ghost_out()
-    e.ghost_in(ghost * 0)
-    mark("deposit")
-    e.fft2(-1)
-    blocks = e.pack()
-    mark("fft_zy")
-    e.solve_x(blocks)           # (P, Gs, Gs, pitch) read as (G, Gs, pitch): this slab's rows of every plane, were they exchanged
-    mark("solve_x")
-    e.unpack(blocks)
-    e.fft2(+1)
-    mark("ifft_yz")
-    e.planes_in(1, 0, e.planes_out(1, Gs, 1))
-    e.planes_in(1, Gs + 1, e.planes_out(1, 1, 2))
-    e.gather_kick_drift(dt)
-    mark("gather_kick_drift")
-    counts = e.outbox_counts().cpu().tolist()
-    e.outbox_records(counts[:P])
-    e.inbox(torch.empty((0, 8), dtype=torch.float32, device="cuda"))
-    mark("migration")
-    torch.cuda.synchronize()
-    if record:
-        for (_, a), (name, b) in zip(marks, marks[1:]):
-            acc[name] += a.elapsed_time(b)
+    def step(record):
+        marks = []
+
+        def mark(name):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+        mark("start")
+        e.deposit()
+        ghost = e.ghost_out()
+        e.ghost_in(ghost * 0)
+        mark("deposit")
+        e.fft2(-1)
+        blocks = e.pack()
+        mark("fft_zy")
+        e.solve_x(blocks)           # (P, Gs, Gs, pitch) read as (G, Gs, pitch): this slab's rows of every plane, were they exchanged
+        mark("solve_x")
+        e.unpack(blocks)
+        e.fft2(+1)
+        mark("ifft_yz")
+        e.planes_in(1, 0, e.planes_out(1, Gs, 1))
+        e.planes_in(1, Gs + 1, e.planes_out(1, 1, 2))
+        e.gather_kick_drift(dt)
+        mark("gather_kick_drift")
+        counts = e.outbox_counts().cpu().tolist()
+        e.outbox_records(counts[:P])
+        e.inbox(torch.empty((0, 8), dtype=torch.float32, device="cuda"))
+        mark("migration")
+        torch.cuda.synchronize()
+        if record:
+            for (_, a), (name, b) in zip(marks, marks[1:]):
+                acc[name] += a.elapsed_time(b)
+
+    step(False)
+    for _ in range(args.steps):
+        step(True)
+    out = {k: round(v / args.steps, 3) for k, v in acc.items()}
+    total = sum(out.values())
+    m_local = G * G * Gs
+    line = {"grid": G, "slabs": P, "slab": rank, "planes": Gs, "particles_in_slab_at_start": n, "hand_written_transforms": bool(e.spectral),
+            "phases_ms": out, "local_ms_per_step": round(total, 3),
+            "local_algorithmic_GB": round((64 * n + 80 * m_local) / 1e9, 2),
+            "local_frac_of_8TBps": round((64 * n + 80 * m_local) / (total * 1e-3) / 8e12, 3)}
+    print(json.dumps(line), flush=True)
+    e.close()
+    return total
 
 
-step(False)
-for _ in range(args.steps):
-    step(True)
-out = {k: round(v / args.steps, 3) for k, v in acc.items()}
-total = sum(out.values())
-m_local = G * G * Gs
-print(json.dumps({"grid": G, "slabs": P, "planes": Gs, "particles_in_slab": e.n, "hand_written_transforms": bool(e.spectral),
-                  "phases_ms": out, "local_ms_per_step": round(total, 3),
-                  "local_algorithmic_GB": round((64 * n + 80 * m_local) / 1e9, 2),
-                  "local_frac_of_8TBps": round((64 * n + 80 * m_local) / (total * 1e-3) / 8e12, 3)}))
-e.close()
+if args.workload == "uniform":
+    rng = np.random.default_rng(7)
+    n = args.n
+    pos = np.empty((n, 3), np.float32)
+    pos[:, 0] = (rng.random(n) * (L / P) * 0.998 + 0.001 * L / P).astype(np.float32)
+    pos[:, 1:] = (rng.random((n, 2)) * L).astype(np.float32)
+    one_slab(0, pos, np.zeros((n, 3), np.float32), np.ones(n, np.float32), np.arange(n, dtype=np.uint32))
+else:
+    # a slab's share of a whole set, with the velocities set to zero so that nobody leaves (the halos are the slab's own
+    # planes: a particle that left would be handed to a neighbour that is not there)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from pm.distributed import slab_of
+    pos, vel, mass = bench.make_workload(args.workload, args.n, L, 1052)
+    owner = slab_of(pos, G, L, P)
+    ids = np.arange(args.n, dtype=np.uint32)
+    totals = {}
+    for r in (range(P) if args.rank < 0 else [args.rank]):
+        mine = owner == r
+        if mine.sum() == 0:
+            continue
+        totals[r] = one_slab(r, pos[mine], np.zeros((int(mine.sum()), 3), np.float32), mass[mine], ids[mine])
+    print(json.dumps({"workload": args.workload, "n": args.n, "grid": G, "slabs": P, "local_ms_per_slab": {str(k): round(v, 3) for k, v in totals.items()},
+                      "largest": round(max(totals.values()), 3), "sum": round(sum(totals.values()), 3)}))
