@@ -56,6 +56,13 @@ static inline corner_t corners(const double *p, int64_t G, double L, double inv)
     c.i = (int64_t)sx; c.j = (int64_t)sy; c.k = (int64_t)sz;
     double dx = sx - (double)c.i, dy = sy - (double)c.j, dz = sz - (double)c.k;
     c.wx0 = 1.0 - dx; c.wx1 = dx; c.wy0 = 1.0 - dy; c.wy1 = dy; c.wz0 = 1.0 - dz; c.wz1 = dz;
+    /* A coordinate whose modulo rounds up to L itself (a tiny negative one: -1e-35 % 100 == 100.0) scales to exactly G.
+     * The reference then indexes plane G of its mesh: an IndexError in plain Python, a write past the array under
+     * numba.  There is nothing to restate; such a particle is put into cell 0 with offset 0, where the periodic box
+     * has it (the library does the same). */
+    if (c.i >= G) c.i -= G;
+    if (c.j >= G) c.j -= G;
+    if (c.k >= G) c.k -= G;
     c.i1 = (c.i + 1) % G; c.j1 = (c.j + 1) % G; c.k1 = (c.k + 1) % G;
     return c;
 }
