@@ -436,6 +436,29 @@ def slab_main(args, rank, world, local_rank):
         l[rank] = n_local
         dist.all_reduce(l)
         loads = [int(x) for x in l]
+    sim.close()
+    # beside the headline: the uniform set of the same size over the same slabs (it divides evenly, the collision does not)
+    also = None
+    if args.workload == "two_galaxy" and not args.no_uniform:
+        pos, vel, mass = make_workload("uniform", n, L, 1052)
+        mine = slab_of(pos, G, L, world) == rank
+        usim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], np.arange(n, dtype=np.uint32)[mine], device_index=local_rank,
+                              capacity=int(mine.sum() * 1.3) + (1 << 20), transpose_chunks=args.transpose_chunks)
+        del pos, vel, mass
+        usim.step(DT, args.warmup)
+        usim.synchronize()
+        t0 = time.perf_counter()
+        usim.step(DT, args.steps)
+        usim.synchronize()
+        ue = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([ue], dtype=torch.float64, device=red)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ue = float(t[0])
+        usim.close()
+        also = {"workload": f"uniform N={n} G={G} L={L} dt={DT}", "value": n * args.steps / ue, "unit": "particle-updates/s",
+                "ms_per_step": ue / args.steps * 1e3,
+                "step_roofline_frac": (64 * n + 80 * G ** 3) / (ue / args.steps) / 1e9 / (HBM_PEAK_GBPS * world)}
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         b_step = 64 * n + 80 * G ** 3
@@ -447,11 +470,10 @@ def slab_main(args, rank, world, local_rank):
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {G // world} planes",
                        "particles_per_slab_at_start": loads, "backend": args.backend if world > 1 else None,
                        "collective_world_size": world, "transpose_chunks": sim.transpose_chunks},
-            "phases_ms": phases,
+            "phases_ms": phases, "uniform_set": also,
             "roofline": {"bound": "hbm", "kernel": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None, "algorithmic_bytes_per_launch": b_step,
                          "ms_per_launch": ms_step}}), flush=True)
-    sim.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
