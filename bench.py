@@ -17,6 +17,7 @@ gather+kick+drift 48N+12M; whole step 64N+80M).  `cpu_baseline` is the CPU oracl
 thread, as the reference ships) timed on one step of the same workload.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -362,7 +363,12 @@ def main():
                          "frac": ach / HBM_PEAK_GBPS,
                          "traffic": measured_traffic([kb[dom][0].split("<")[0]], per_launch=True) if headline else None,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": kper[dom],
-                         "launches_timed": kernels[dom][1]},
+                         "launches_timed": kernels[dom][1],
+                         # the two longest launches are within a few microseconds of each other on this workload and
+                         # change places from run to run: every priced launch, longest first, against the same peak
+                         "ranking": [{"kernel": kb[k][0].replace("<G,", f"<{G},"), "ms_per_launch": round(kper[k], 5),
+                                      "frac": round(kb[k][1] / (kper[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                                     for k in sorted((k for k in kb if kb[k][1] > 0 and kper[k] > 0), key=lambda k: -kper[k])]},
             # the whole step against 64N + 80M (the staged pipeline's compulsory traffic, every mesh written and read once)
             # and against what THIS pipeline cannot avoid (fused: no density mesh, no gradient meshes: 64N + 40M)
             "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved": b_step / (ms_step * 1e-3) / 1e9,
@@ -399,7 +405,9 @@ def slab_main(args, rank, world, local_rank):
     red = "cuda" if args.backend == "nccl" else "cpu"        # where the few scalars reduced below live
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # (a rank that never arrives should end the run in minutes, not after the library's ten)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=240))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     n, G, L = args.n, args.grid, BOX
