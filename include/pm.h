@@ -48,11 +48,15 @@ enum {
     PM_FLAG_NGP = 8u,         /* pm_create only: pm_step runs the nearest-grid-point branch (CIC_interpolation = False,
                                  main.py:9, 40-41), whose meshes and forces are float64 */
     PM_FLAG_ROCFFT_ONLY = 4u, /* pm_create only: 3-D rocFFT plans for every grid size (no hand-written column FFT) */
-    PM_FLAG_F64 = 32u         /* pm_create only: pm_step runs the cloud-in-cell branch with every array in float64 -- what
+    PM_FLAG_F64 = 32u,        /* pm_create only: pm_step runs the cloud-in-cell branch with every array in float64 -- what
                                  main.py:50-60 computes when the mesh of functions.py:22, the forces of functions.py:102 and
                                  the positions after main.py:60 are float64.  The reference has no such switch: this is the
                                  build mode that is held to 1e-12 against a float64 restatement.  Particles must be given
                                  as PM_F64 positions and velocities; not tuned */
+    PM_FLAG_FULL_SORT = 64u   /* the particles are brought into cell order by sorting all of them every time.  Without it
+                                 a step in which few particles changed their cell (the drift counts them) puts the new
+                                 order together from the old one -- the movers are sorted and merged in -- which gives
+                                 the same order and is faster; the flag is there to compare the two */
 };
 
 /* stages reported by pm_stage_times, in this order */
@@ -174,6 +178,10 @@ int pm_set_mesh(pm_ctx *ctx, int which, const float *in /* G*G*G */);
  * in cell order (cell (i,j,k) as functions.py:27-39 computes it), perm[r] =
  * its index in the caller's original order.  Ties keep storage order. */
 int pm_get_cell_keys(pm_ctx *ctx, int64_t *keys, int64_t *perm);
+/* How the last binning got its order (a diagnostic of this engine; the reference has no cell order).  Returns 1 if it
+ * was put together from the order of the step before, with *movers = the particles that had changed their cell; 0 if
+ * the whole set was sorted (*movers = 0); negative on error.  Synchronises. */
+int pm_last_binning(pm_ctx *ctx, int64_t *movers);
 
 /* compute_kinetic_energy(velocities, masses) and compute_potential_energy(positions, masses,
  * potential, grid_size, box_size): functions.py:352-361, call sites main.py:65-66.  Uses the live

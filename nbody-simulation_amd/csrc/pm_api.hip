@@ -79,17 +79,45 @@ int alloc_particles(pm_ctx *c)
     return PM_OK;
 }
 
+// Buffers of the binning that starts from the cell order of the step before (every particle may be a mover).
+int prepare_rebin(pm_ctx *c)
+{
+    if (c->rb_ctl) return PM_OK;
+    const size_t cap = (size_t)c->cap;
+    TRY(dalloc(c, &c->key_alt, cap + 4));
+    HIP_TRY(c, hipMalloc((void **)&c->rb_ctl, pm_rebin_ctl_bytes(c->cap)));
+    TRY(dalloc(c, &c->rb_before, cap / 64 + 2));
+    for (int u = 0; u < 2; ++u) { TRY(dalloc(c, &c->rb_key[u], cap + 4)); TRY(dalloc(c, &c->rb_slot[u], cap + 4)); }
+    TRY(dalloc(c, &c->rb_at, cap + 4));
+    return PM_OK;
+}
+
 int ensure_binned(pm_ctx *c)
 {
     if (c->binned) return PM_OK;
     stage_timer t(c, PM_STAGE_BIN);
     HIP_TRY(c, pm_settle_velocities(c));        // src is about to be overwritten
+    // The drift leaves the new keys of the slots (key_in) and an estimate of how many of them differ from the old ones
+    // (key_out, still the sorted keys of this storage order).  Few: the new order is put together from the old one.
+    // The estimate is a step or two old and decides speed only: the kernels count for themselves, and either way gives
+    // the same order.
+    const bool few = c->order_known && c->keys_fresh && c->movers_marked && c->movers_seen && c->n >= PM_REBIN_MIN && c->n < ((int64_t)1 << 30)
+                     && !(c->flags & PM_FLAG_FULL_SORT) && (int64_t)*c->movers_seen * 16 <= c->n;
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
     c->keys_fresh = false;      // the sort consumes key_in
-    HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
+    c->movers_marked = false;
+    if (few) {
+        TRY(prepare_rebin(c));
+        HIP_TRY(c, pm_rebin_incremental(c, bits_for(c->g.M)));
+        c->last_incremental = true;
+    } else {
+        c->last_incremental = false;
+        HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
+    }
     HIP_TRY(c, pm_launch_reorder(c));
     HIP_TRY(c, pm_launch_row_start(c));
     c->binned = true;
+    c->order_known = true;
     // forces / forces64 are indexed by the storage slots of before the reorder: no longer attached to their particles
     c->have_forces = false; c->have_forces64 = false;
     return PM_OK;
@@ -132,6 +160,14 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipHostMalloc((void **)&c->units_seen, sizeof(uint32_t), hipHostMallocDefault));
     *c->units_seen = 1;
     HIP_TRY(c, hipHostGetDevicePointer((void **)&c->units_seen_dev, (void *)c->units_seen, 0));
+    if (!c->slab) {
+        HIP_TRY(c, hipHostMalloc((void **)&c->movers_seen, sizeof(uint32_t), hipHostMallocDefault));
+        *c->movers_seen = 0xffffffffu;      // nothing known yet: the first binnings sort the whole set
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->movers_seen_dev, (void *)c->movers_seen, 0));
+        TRY(dalloc(c, &c->rb_mask, (size_t)c->cap / 64 + 2));
+        TRY(dalloc(c, &c->mover_count, 1));
+        HIP_TRY(c, hipMemset(c->mover_count, 0, sizeof(unsigned long long)));
+    }
     if (c->flags & PM_FLAG_TIMING) TRY(make_timing_events(c));
 
     // the deposit reads keys and fraction records in groups of four: three entries of slack
@@ -262,6 +298,9 @@ void pm_destroy(pm_ctx *c)
                 if (c->ev[s][r][k]) hipEventDestroy(c->ev[s][r][k]);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->units_seen) hipHostFree((void *)c->units_seen);
+    if (c->movers_seen) hipHostFree((void *)c->movers_seen);
+    hipFree(c->mover_count); hipFree(c->key_alt); hipFree(c->rb_ctl); hipFree(c->rb_mask); hipFree(c->rb_before); hipFree(c->rb_at);
+    for (int u = 0; u < 2; ++u) { hipFree(c->rb_key[u]); hipFree(c->rb_slot[u]); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->copy) { hipStreamSynchronize(c->copy); hipStreamDestroy(c->copy); }
@@ -315,7 +354,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     c->pos_in_f64 = c->pos_f64 = (pos_dtype == PM_F64);
     c->vel_f64 = (vel_dtype == PM_F64);
     TRY(alloc_particles(c));
-    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false;
+    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
     size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
     if (n > 0) {
         // staging: positions (n,3), then the masses behind them
@@ -352,7 +391,7 @@ int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *par
     c->pos_in_f64 = c->pos_f64 = false;
     c->vel_f64 = false;
     TRY(alloc_particles(c));
-    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false;
+    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
     HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PM_OK;
@@ -694,6 +733,19 @@ int pm_get_cell_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
     return PM_OK;
 }
 
+int pm_last_binning(pm_ctx *c, int64_t *movers)
+{
+    if (!c || !movers) return PM_EINVAL;
+    *movers = 0;
+    if (!c->last_incremental) return 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t ctl[PM_RB_WORDS];
+    HIP_TRY(c, hipMemcpyAsync(ctl, c->rb_ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *movers = (int64_t)ctl[PM_RB_MOVERS];
+    return 1;
+}
+
 int pm_energies(pm_ctx *c, double *ke, double *pe)
 {
     TRY(whole_mesh(c));
@@ -730,7 +782,7 @@ int pm_deposit_ngp(pm_ctx *c)
     TRY(dalloc(c, &c->density64, (size_t)c->g.M));
     // the sort scratch (keys, src) is shared with the cloud-in-cell binning: settle what depends on it
     HIP_TRY(c, pm_settle_velocities(c));
-    c->binned = false; c->keys_fresh = false;
+    c->binned = false; c->keys_fresh = false; c->order_known = false;
     uint32_t *bad = (uint32_t *)(c->diag + 2 * 1024 + 2);
     HIP_TRY(c, hipMemsetAsync(bad, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->density64, 0, (size_t)c->g.M * sizeof(double), c->stream));
@@ -928,14 +980,15 @@ static int step_ngp(pm_ctx *c, double dt)
     stage_timer t(c, PM_STAGE_GATHER);
     HIP_TRY(c, pm_launch_ngp_gather(c, dt, true, nullptr));
     c->pos_f64 = false;      // positions are float32 from the first drift on (main.py:60)
-    c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false;
+    c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
     return PM_OK;
 }
 
 int pm_set_flags(pm_ctx *c, unsigned flags)
 {
     if (!c) return PM_EINVAL;
-    if (flags & ~(unsigned)(PM_FLAG_TIMING | PM_FLAG_FUSED_GRADIENT)) return fail(c, PM_EINVAL, "only PM_FLAG_TIMING and PM_FLAG_FUSED_GRADIENT can change");
+    if (flags & ~(unsigned)(PM_FLAG_TIMING | PM_FLAG_FUSED_GRADIENT | PM_FLAG_FULL_SORT))
+        return fail(c, PM_EINVAL, "only PM_FLAG_TIMING, PM_FLAG_FUSED_GRADIENT and PM_FLAG_FULL_SORT can change");
     flags |= c->flags & (PM_FLAG_ROCFFT_ONLY | PM_FLAG_NGP | PM_FLAG_F64);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

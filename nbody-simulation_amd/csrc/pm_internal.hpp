@@ -54,6 +54,18 @@ template <typename T> struct pm_vrec;
 template <> struct alignas(16) pm_vrec<float> { float x, y, z; uint32_t id; };
 template <> struct alignas(16) pm_vrec<double> { double x, y, z; uint32_t id; uint32_t pad; };
 
+// words of pm_ctx::rb_ctl (pm_rebin.hip): the ticket that hands out tiles, and the movers found (the device-side count
+// of the sort that follows)
+enum { PM_RB_TICKET = 0, PM_RB_MOVERS = 1, PM_RB_WORDS = 8 };
+
+constexpr int64_t PM_REBIN_MIN = 1 << 20;       // particle sets below this are always sorted whole
+// What the drift reports about the particles that changed their cell.  mask (may be null): a bit per storage slot, in
+// words of 64 slots, set where the particle's new cell key differs from its old one.  A sample of the workgroups also
+// counts them for the host: *count holds the waves that have reported (upper half) and the movers they saw (lower
+// half); the last of `expect` waves writes the estimate for the whole set to *seen (pinned host memory) and clears the
+// word.  expect == 0: nothing is counted.
+struct pm_mover_probe { unsigned long long *count; volatile uint32_t *seen; uint32_t expect; uint64_t *mask; };
+
 struct pm_ctx {
     pm_geom g{};
     int device = 0;
@@ -94,6 +106,17 @@ struct pm_ctx {
 
     // binning scratch
     uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;
+    // binning from the cell order of the step before (pm_rebin.hip; buffers allocated on first use)
+    bool last_incremental = false;      // the last binning started from the order before it
+    bool movers_marked = false;         // rb_mask holds the movers of the last drift (for the keys in key_in)
+    bool order_known = false;           // key_out holds the sorted keys of the live storage order, row_start its rows
+    uint32_t *key_alt = nullptr;        // takes turns with key_out
+    uint32_t *rb_ctl = nullptr;         // PM_RB_WORDS control words, then a look-back word per tile
+    uint64_t *rb_mask = nullptr;        // per 64 slots: which hold a mover (written by the drift; allocated with the context)
+    uint32_t *rb_before = nullptr;      // per 64 slots: movers in the slots before
+    uint32_t *rb_key[2] = {}, *rb_slot[2] = {}, *rb_at = nullptr;       // the movers: new key and slot (unsorted, sorted), where they go in
+    unsigned long long *mover_count = nullptr;  // pm_mover_probe::count
+    volatile uint32_t *movers_seen = nullptr, *movers_seen_dev = nullptr;      // pinned host word: estimate of the movers of a recent drift
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
@@ -200,6 +223,12 @@ hipError_t pm_launch_cell_keys(pm_ctx *c);
 hipError_t pm_launch_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params);
 int pm_generate_param_count(int kind);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);          // key_in -> key_out (sorted), src (storage slot of each sorted entry)
+// the same from the cell order of the step before (key_out, row_start) and the new keys (key_in); key_out / key_alt swap
+hipError_t pm_rebin_incremental(pm_ctx *c, int bits);
+size_t pm_rebin_ctl_bytes(int64_t cap);
+size_t pm_sort_counted_tmp_bytes(int64_t n_max);
+hipError_t pm_sort_pairs_counted(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n_max,
+                                 const uint32_t *n_dev, int bits, int device, hipStream_t s);
 hipError_t pm_launch_reorder(pm_ctx *c);
 size_t pm_sort_tmp_bytes(int64_t cap);
 hipError_t pm_settle_velocities(pm_ctx *c);     // must run before src is overwritten by a new sort

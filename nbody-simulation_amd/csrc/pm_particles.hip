@@ -782,7 +782,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
          pm_vrec<TV> *__restrict__ Vout, const uint32_t *__restrict__ vmap,
          const float *__restrict__ gx, const float *__restrict__ gy, const float *__restrict__ gz,
          const float *__restrict__ phi, float *__restrict__ forces, uint32_t *__restrict__ key_next, int64_t n, pm_geom g,
-         double dt, bool integrate, outbox_t ob)
+         double dt, bool integrate, outbox_t ob, pm_mover_probe probe)
 {
     int64_t r = (int64_t)xcd_block<PM_GATHER_XCD>() * BLOCK + threadIdx.x;
     if (r >= n) return;
@@ -802,6 +802,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
             c.i = g.i0;
         }
     }
+    const uint32_t k_old = cell_key(c, g);              // (kept for the count of movers at the end: one register instead of the cell's three)
     const int i1 = (c.i + 1 == G) ? 0 : c.i + 1, j1 = (c.j + 1 == G) ? 0 : c.j + 1, k1 = (c.k + 1 == G) ? 0 : c.k + 1;
     const double wx[2] = {1.0 - c.dx, c.dx}, wy[2] = {1.0 - c.dy, c.dy}, wz[2] = {1.0 - c.dz, c.dz};
     const int ii[2] = {c.i, i1}, jj[2] = {c.j, j1}, kk[2] = {c.k, k1};
@@ -905,6 +906,27 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     const cell_t cn = locate(o, g);
     const uint32_t kn = cell_key(cn, g);
     key_next[r] = kn;
+    if constexpr (!SLAB) {
+        // Which particles changed their cell: a bit per slot for the next binning, which may start from this order.
+        // And how many, from every 64th workgroup (full ones only), for the host to choose that binning by: one counter
+        // update per wave; the wave that reports last hands the estimate over.
+        const unsigned long long moved = __ballot(kn != k_old);
+        if (probe.mask != nullptr && lane_id() == 0) probe.mask[r >> 6] = moved;
+        const uint32_t blk = (uint32_t)(r / BLOCK);
+        if (probe.expect != 0u && (blk & 63u) == 0u && (int64_t)(blk + 1u) * BLOCK <= n) {
+            if (lane_id() == 0) {
+                // one word holds both the waves that have reported (upper half) and their movers (lower half): the
+                // wave that completes the count has the sum in hand, and no fence is needed to order two words
+                const unsigned long long mine = (1ull << 32) | (unsigned long long)__popcll(moved);
+                const unsigned long long all = atomicAdd(probe.count, mine) + mine;
+                if ((uint32_t)(all >> 32) == probe.expect) {
+                    atomicExch(probe.count, 0ull);
+                    const uint32_t seen = (uint32_t)all;
+                    *probe.seen = seen > 0x03ffffffu ? 0xffffffffu : seen * 64u;
+                }
+            }
+        }
+    }
     if constexpr (SLAB && sizeof(TV) == 4) {
         const bool leaves = kn == (uint32_t)g.Gs * (uint32_t)G * (uint32_t)G;
         // one counter update per wave
@@ -1157,18 +1179,25 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
     const pm_vrec<TV> *vin = V[c->vcur];
     pm_vrec<TV> *vout = c->v_stale ? V[1 - c->vcur] : V[c->vcur];
     const uint32_t *vmap = c->v_stale ? c->src : nullptr;
+    // the drift of a whole-mesh context also estimates how many particles changed their cell (pm_mover_probe)
+    pm_mover_probe probe{c->mover_count, c->movers_seen_dev, 0u, nullptr};
+    if (integrate && !c->slab && c->mover_count && n >= PM_REBIN_MIN) {
+        probe.expect = 4u * (uint32_t)((n / BLOCK + 63) / 64);
+        probe.mask = c->rb_mask;
+        c->movers_marked = c->rb_mask != nullptr;
+    }
     auto launch = [&](auto mapped) {
         constexpr bool M = decltype(mapped)::value;
         if (c->slab) {
             if constexpr (sizeof(TP) == 4 && sizeof(TV) == 4) {
                 const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap};
                 k_gather<float, float, true, true, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces,
-                                                                                           c->key_in, n, c->g, dt, integrate, ob);
+                                                                                           c->key_in, n, c->g, dt, integrate, ob, probe);
             }
         } else if (fused)
-            k_gather<TP, TV, true, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate, outbox_t{});
+            k_gather<TP, TV, true, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate, outbox_t{}, probe);
         else
-            k_gather<TP, TV, false, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate, outbox_t{});
+            k_gather<TP, TV, false, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate, outbox_t{}, probe);
     };
     if (vmap) launch(std::true_type{});
     else launch(std::false_type{});

@@ -47,8 +47,9 @@ constexpr unsigned COUNT_ITEMS = 16;
 
 template <typename K, unsigned RADIX>
 __global__ void __launch_bounds__(PM_COUNT_BLOCK)
-k_digit_counts(const K *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t size, unsigned bits)
+k_digit_counts(const K *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t size, unsigned bits, const uint32_t *__restrict__ size_dev)
 {
+    if (size_dev) size = *size_dev;                     // the number of keys is known on the device only (at most the `size` given)
     constexpr unsigned ITEMS = COUNT_ITEMS, MAX_PLACES = (8 * sizeof(K) + RADIX - 1) / RADIX, SIZE = 1u << RADIX;
     static_assert(ITEMS % 4 == 0, "keys are loaded four at a time");
     extern __shared__ uint32_t table[];                 // places * SIZE counters
@@ -191,11 +192,18 @@ template <typename K, unsigned RADIX> constexpr size_t pass_lds_bytes()
 #define PM_SORT_LOOK 4
 #endif
 constexpr uint32_t LOOK = PM_SORT_LOOK;             // states of earlier tiles requested at a time
-template <typename K, typename S, unsigned RADIX, bool COUNTED, class Sink>
+// ON_DEVICE: the number of pairs is *n_dev, known on the device only.  The grid then has a fixed, modest number of
+// workgroups, each of which takes tiles until none is left -- so that a sort of few pairs (or of none) does not pay for
+// the start of as many workgroups as the most pairs there could be would need.
+template <typename K, typename S, unsigned RADIX, bool COUNTED, bool ON_DEVICE, class Sink>
 __global__ void __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(PM_PASS_WAVES)))
 k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n, const uint32_t *__restrict__ digit_base,
-             S *__restrict__ states, uint32_t *__restrict__ ticket, unsigned bit, uint32_t mask, Sink sink)
+             S *__restrict__ states, uint32_t *__restrict__ ticket, unsigned bit, uint32_t mask, Sink sink, const uint32_t *__restrict__ n_dev)
 {
+    if constexpr (ON_DEVICE) {
+        n = *n_dev;
+        if ((uint64_t)blockIdx.x * SORT_TILE >= n) return;      // more workgroups than tiles: these take no ticket
+    }
     constexpr uint32_t SIZE = 1u << RADIX;
     constexpr size_t HIST = (size_t)SORT_WAVES * SIZE * sizeof(uint32_t), KEYS = (size_t)SORT_TILE * sizeof(K);
     extern __shared__ __align__(16) unsigned char lds[];
@@ -208,12 +216,16 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
     const int t = threadIdx.x, lane = lane_id(), w = wave_id();
     (void)lane;
 
+  // (Measured and not kept: a ticket that is good for several consecutive tiles.  A workgroup then publishes the count of
+  // its second tile only after its first is done, which waits for the second tile of the workgroup before it: the
+  // pass becomes one chain, 8 ms instead of 90 us.)
+  for (;;) {                                            // (one turn unless ON_DEVICE)
     if (t == 0) misc[0] = atomicAdd(ticket, 1u);
     for (uint32_t q = t; q < SORT_WAVES * SIZE; q += SORT_BLOCK) whist[q] = 0u;
     __syncthreads();
     const uint32_t tile = misc[0];
     const uint32_t base = tile * (uint32_t)SORT_TILE;
-    if (base >= n) return;                              // (never: the grid has exactly the tiles there are)
+    if (base >= n) return;                              // (ON_DEVICE: no tile is left; else never: the grid has exactly the tiles there are)
     const uint32_t count = n - base < (uint32_t)SORT_TILE ? n - base : (uint32_t)SORT_TILE;
     const uint32_t first = (uint32_t)w * (64u * SORT_ITEMS) + (uint32_t)lane;      // place in the tile of item 0
 
@@ -335,6 +347,9 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
         dest[i] = gdelta[digit_of(key[i], bit, mask)] + q;
     }
     sink.template put<sizeof(S) == 4>(dest, key, val, live);
+    if constexpr (!ON_DEVICE) return;
+    __syncthreads();                                    // the tile's keys have been read out of LDS: the next tile may use it
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -376,33 +391,48 @@ unsigned place_bits(unsigned bits)
     return (bits + 8) / 9 < (bits + 7) / 8 ? 9 : 8;
 }
 
+#ifndef PM_SORT_DEVICE_GRID
+#define PM_SORT_DEVICE_GRID 512
+#endif
 template <typename K, typename S, unsigned RADIX, bool COUNTED, class Sink>
 hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, size_t n, const uint32_t *digit_base, void *states, uint32_t *ticket, unsigned bit,
-                       unsigned now, Sink sink, int device, hipStream_t s, pm_ctx *timed)
+                       unsigned now, Sink sink, int device, hipStream_t s, pm_ctx *timed, const uint32_t *n_dev)
 {
     constexpr size_t lds = pass_lds_bytes<K, RADIX>();
-    auto kernel = k_radix_pass<K, S, RADIX, COUNTED, Sink>;
-    if (lds > 64 * 1024) {
+    auto allow = [&](const void *kernel) -> hipError_t {
+        if (lds <= 64 * 1024) return hipSuccess;
         // more LDS than a kernel gets by default: allowed once per kernel and device (a bit per device; setting it
         // twice from two threads is harmless)
-        static std::atomic<uint64_t> allowed{0};
+        static std::atomic<uint64_t> allowed[2] = {};
+        std::atomic<uint64_t> &a = allowed[n_dev ? 1 : 0];
         const uint64_t bit_of = 1ull << (device & 63);
-        if (!(allowed.load(std::memory_order_acquire) & bit_of)) {
-            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            allowed.fetch_or(bit_of, std::memory_order_release);
-        }
-    }
+        if (a.load(std::memory_order_acquire) & bit_of) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) a.fetch_or(bit_of, std::memory_order_release);
+        return e;
+    };
     pm_timer timer(timed, PM_NSTAGES + PM_KERNEL_SORT_PASS);
-    kernel<<<p.tiles, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink);
+    if (n_dev) {
+        auto kernel = k_radix_pass<K, S, RADIX, COUNTED, true, Sink>;
+        hipError_t e = allow((const void *)kernel);
+        if (e != hipSuccess) return e;
+        const unsigned grid = p.tiles < (unsigned)PM_SORT_DEVICE_GRID ? p.tiles : (unsigned)PM_SORT_DEVICE_GRID;
+        kernel<<<grid, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink, n_dev);
+    } else {
+        auto kernel = k_radix_pass<K, S, RADIX, COUNTED, false, Sink>;
+        hipError_t e = allow((const void *)kernel);
+        if (e != hipSuccess) return e;
+        kernel<<<p.tiles, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink, n_dev);
+    }
     return hipGetLastError();
 }
 
 // Sorts n (key, value) pairs by the low `bits` bits of the keys, values going in as 0, 1, 2, ... (vin == nullptr) or
-// from vin; the sorted pairs end in kout / vout -- through `last`, the sink of the final pass.
+// from vin; the sorted pairs end in kout / vout -- through `last`, the sink of the final pass.  n_dev != nullptr: the
+// number of pairs is *n_dev <= n, read by the kernels (0 pairs: every kernel leaves at once).
 template <typename K, typename S, unsigned RADIX, class LastSink>
 hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits, LastSink last,
-                      int device, hipStream_t s, pm_ctx *timed)
+                      int device, hipStream_t s, pm_ctx *timed, const uint32_t *n_dev)
 {
     const sort_plan p = plan_sort(n, bits, RADIX, sizeof(K));
     if (p.bytes > tmp_bytes) return hipErrorOutOfMemory;
@@ -416,7 +446,7 @@ hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const 
     const size_t per_count = (size_t)PM_COUNT_BLOCK * COUNT_ITEMS;
     const size_t want = (n + per_count - 1) / per_count;
     k_digit_counts<K, RADIX><<<(unsigned)(want < PM_COUNT_GRID ? want : PM_COUNT_GRID), PM_COUNT_BLOCK, (size_t)p.places * p.size * sizeof(uint32_t), s>>>(
-        kin, counts, (uint32_t)n, bits);
+        kin, counts, (uint32_t)n, bits, n_dev);
     k_digit_offsets<RADIX><<<p.places, SORT_BLOCK, 0, s>>>(counts);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // the passes alternate between the scratch and the output so that the last one ends in the output
@@ -431,12 +461,12 @@ hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const 
         S *st = states + (size_t)place * p.size * p.tiles;
         const bool counted = from_input && vin == nullptr;
         if (place + 1 == p.places) {
-            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed)
-                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed);
+            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed, n_dev)
+                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed, n_dev);
         } else {
             const pair_sink<K> mid{ko, vo};
-            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed)
-                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed);
+            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed, n_dev)
+                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed, n_dev);
         }
         if (e != hipSuccess) return e;
         from_input = false;
@@ -447,15 +477,15 @@ hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const 
 
 template <typename K, class LastSink>
 hipError_t sort_dispatch(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits, LastSink last,
-                         int device, hipStream_t s, pm_ctx *timed)
+                         int device, hipStream_t s, pm_ctx *timed, const uint32_t *n_dev = nullptr)
 {
     if (n == 0) return hipSuccess;
     if (bits < 1) bits = 1;
     const bool wide = n >= ((size_t)1 << 30);
     auto with_state = [&](auto radix) {
         constexpr unsigned R = decltype(radix)::value;
-        return wide ? sort_pairs<K, uint64_t, R>(tmp, tmp_bytes, kin, kout, vin, vout, n, bits, last, device, s, timed)
-                    : sort_pairs<K, uint32_t, R>(tmp, tmp_bytes, kin, kout, vin, vout, n, bits, last, device, s, timed);
+        return wide ? sort_pairs<K, uint64_t, R>(tmp, tmp_bytes, kin, kout, vin, vout, n, bits, last, device, s, timed, n_dev)
+                    : sort_pairs<K, uint32_t, R>(tmp, tmp_bytes, kin, kout, vin, vout, n, bits, last, device, s, timed, n_dev);
     };
     if constexpr (sizeof(K) == 8) return with_state(std::integral_constant<unsigned, 8>{});
     else {
@@ -487,6 +517,16 @@ hipError_t pm_sort_pairs(pm_ctx *c, int bits)
 {
     return sort_dispatch<uint32_t>(c->sort_tmp, c->sort_tmp_bytes, c->key_in, c->key_out, nullptr, c->src, (size_t)c->n, (unsigned)bits,
                                    pair_sink<uint32_t>{c->key_out, c->src}, c->device, c->stream, c);
+}
+
+// *n_dev <= n_max pairs of 32-bit keys, the count known on the device only: (kin, vin) -> (kout, vout); vin == nullptr: the
+// values are 0, 1, 2, ...
+size_t pm_sort_counted_tmp_bytes(int64_t n_max) { return tmp_bytes_for((size_t)n_max, sizeof(uint32_t), 32); }
+
+hipError_t pm_sort_pairs_counted(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n_max,
+                                 const uint32_t *n_dev, int bits, int device, hipStream_t s)
+{
+    return sort_dispatch<uint32_t>(tmp, tmp_bytes, kin, kout, vin, vout, n_max, (unsigned)bits, pair_sink<uint32_t>{kout, vout}, device, s, nullptr, n_dev);
 }
 
 // Particles leaving a slab: (destination slab, particle id) keys with the outbox slot as value.

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PM_LIBRARY") or os.path.join(os.path.dirname(_HERE), 
 
 PM_F32, PM_F64 = 0, 1
 MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ, SLAB_ZSPECTRUM = range(6)
-FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP, FLAG_F64 = 1, 2, 4, 8, 32
+FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP, FLAG_F64, FLAG_FULL_SORT = 1, 2, 4, 8, 32, 64
 IC_KINDS = {"uniform": 0, "two_galaxy": 1, "disk": 2}
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
 KERNELS = ("sort_pass", "reorder", "deposit_rows", "col_y_fwd", "col_x_green", "col_y_inv", "row_inv", "gather")
@@ -75,6 +75,7 @@ SIGNATURES = {
     "pm_slab_inverse_planes": (_int, [_c_p, _c_p, _int, _int]),
     "pm_stage_times": (_int, [_c_p, _c_p, _c_p]),
     "pm_kernel_times": (_int, [_c_p, _c_p, _c_p]),
+    "pm_last_binning": (_int, [_c_p, _c_p]),
     "pm_set_flags": (_int, [_c_p, ctypes.c_uint]),
     "pm_set_stream": (_int, [_c_p, _c_p]),
     "pm_synchronize": (_int, [_c_p]),

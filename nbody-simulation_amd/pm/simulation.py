@@ -40,8 +40,10 @@ class Simulation:
 
     def __init__(self, grid_size, box_size, positions=None, velocities=None, masses=None,
                  interpolation="CIC", capacity=None, device=0, timing=False, fused_gradient=False, rocfft_only=False,
-                 float64=False):
-        """float64=True (cloud-in-cell only) makes step / run the float64 build mode (PM_FLAG_F64): mesh, forces,
+                 float64=False, full_sort=False):
+        """full_sort=True (PM_FLAG_FULL_SORT) sorts the whole set into cell order every step instead of merging the few
+        particles that changed their cell into the order of the step before (same order; for comparisons).
+        float64=True (cloud-in-cell only) makes step / run the float64 build mode (PM_FLAG_F64): mesh, forces,
         positions and velocities all float64 -- the reference's loop with float64 in place of float32 everywhere."""
         if interpolation not in ("CIC", "NGP"):
             raise ValueError(f"interpolation must be 'CIC' or 'NGP' (main.py:9, 40-41), got {interpolation!r}")
@@ -55,7 +57,8 @@ class Simulation:
         self.capacity = int(capacity if capacity is not None else max(n, 1))
         flags = ((L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
                  | (L.FLAG_ROCFFT_ONLY if rocfft_only else 0) | (L.FLAG_NGP if interpolation == "NGP" else 0)
-                 | (L.FLAG_F64 if float64 else 0))
+                 | (L.FLAG_F64 if float64 else 0) | (L.FLAG_FULL_SORT if full_sort else 0))
+        self.full_sort = bool(full_sort)
         self.ctx = self.lib.pm_create(self.grid_size, float(box_size), self.capacity, int(device), flags)
         if not self.ctx:
             raise L.PMError("pm_create failed: " + self.lib.pm_last_error(None).decode())
@@ -208,7 +211,8 @@ class Simulation:
         self._ck(self.lib.pm_synchronize(self.ctx))
 
     def set_flags(self, timing=False, fused_gradient=False):        # the interpolation branch stays as created
-        flags = (L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
+        flags = ((L.FLAG_TIMING if timing else 0) | (L.FLAG_FUSED_GRADIENT if fused_gradient else 0)
+                 | (L.FLAG_FULL_SORT if self.full_sort else 0))
         self._ck(self.lib.pm_set_flags(self.ctx, flags))
 
     # ---- state -------------------------------------------------------------------------
@@ -258,6 +262,15 @@ class Simulation:
         keys, perm = np.empty(n, np.int64), np.empty(n, np.int64)
         self._ck(self.lib.pm_get_cell_keys(self.ctx, L.ptr(keys), L.ptr(perm)))
         return keys, perm
+
+    def last_binning(self):
+        """(incremental, movers) of the last binning (pm_last_binning)."""
+        import ctypes
+        movers = ctypes.c_int64(0)
+        rc = self.lib.pm_last_binning(self.ctx, ctypes.byref(movers))
+        if rc < 0:
+            self._ck(rc)
+        return bool(rc), int(movers.value)
 
     def stage_times(self):
         """{stage: (milliseconds, calls)} since the last call (needs timing=True)."""

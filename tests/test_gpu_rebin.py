@@ -1,0 +1,91 @@
+"""The binning that starts from the cell order of the step before (csrc/pm_rebin.hip) against the sort of the whole set
+(PM_FLAG_FULL_SORT): the cell order is `stable sort of the storage order by cell key` (functions.py:27-39 defines the
+cells) whichever way it is computed, so keys, permutation, positions and velocities must agree bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+import pm  # noqa: E402
+
+N = 1 << 21          # the incremental path is for sets of 2^20 particles and more
+L = 100.0
+
+
+def make(seed, sigma, clumped=False):
+    rng = np.random.default_rng(seed)
+    if clumped:
+        pos = (0.5 * L + rng.normal(0, 0.04 * L, (N, 3))) % L
+    else:
+        pos = rng.random((N, 3)) * L
+    vel = rng.normal(0, sigma, (N, 3))
+    # (light particles: the kicks of six steps stay small beside these velocities, so the movers stay few)
+    return pos.astype(np.float32), vel.astype(np.float32), np.full(N, 1e-4, np.float32)
+
+
+def run_pair(G, pos, vel, mass, dts, fused=True):
+    """The same steps on two contexts, one of them sorting everything: compares after every step, returns what the
+    incremental one reported per step."""
+    reports = []
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused) as a, \
+            pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused, full_sort=True) as b:
+        for dt in dts:
+            a.step(dt, 1)
+            b.step(dt, 1)
+            # the drift's estimate of its movers reaches the host without anyone waiting for it: wait here, so that the
+            # choice the next binning makes is the same in every run
+            a.synchronize(), b.synchronize()
+            # (the binning of a step happens at its start: deposit once more to bin the drifted particles)
+            a.deposit(), b.deposit()
+            ka, pa = a.cell_keys()
+            kb, pb = b.cell_keys()
+            assert np.array_equal(ka, kb)
+            assert np.array_equal(pa, pb)
+            assert np.all(np.diff(ka) >= 0)
+            reports.append(a.last_binning())
+            assert b.last_binning() == (False, 0)
+        assert np.array_equal(a.positions(), b.positions())
+        assert np.array_equal(a.velocities(), b.velocities())
+    return reports
+
+
+@pytest.mark.parametrize("G,clumped", [(128, False), (64, True), (100, False)])
+def test_few_movers_same_order(G, clumped):
+    pos, vel, mass = make(3, 2.0, clumped)
+    rep = run_pair(G, pos, vel, mass, [0.01] * 6)
+    for inc, movers in rep:
+        assert inc and 0 < movers < N // 8, rep
+
+
+def test_nearly_everyone_moves():
+    """The drift estimates its movers from every 64th workgroup of 256 slots.  Here exactly those slots hold particles
+    at rest and all others move a cell or more: the estimate says `none`, the binning starts from the old order, finds
+    63 of 64 particles moved -- and still arrives at the order the sort of everything gives."""
+    G = 128
+    pos, _, _ = make(5, 0.0)
+    with pm.Simulation(G, L, pos, np.zeros((N, 3), np.float32), np.ones(N, np.float32)) as probe:
+        probe.deposit()
+        _, perm = probe.cell_keys()                      # perm[r]: the particle stored at slot r after the first binning
+    slot = np.empty(N, np.int64)
+    slot[perm] = np.arange(N)
+    sampled = (slot // 256) % 64 == 0
+    vel = np.where(sampled[:, None], 0.0, 3.0 * L / G).astype(np.float32) * np.ones((1, 3), np.float32)
+    mass = np.full(N, 1e-30, np.float32)                 # no forces to speak of: a particle at rest stays where it is
+    rep = run_pair(G, pos, vel, mass, [1.0, 1.0])
+    assert rep[0] == (True, int((~sampled).sum())), rep
+    assert rep[1] == (False, 0), rep                     # (the slots sampled now hold other particles: the estimate has caught up)
+
+
+def test_staged_pipeline_and_wrapping_movers():
+    """particles that cross the box's faces change to far-away keys; the staged pipeline (separate meshes) bins the same way"""
+    rng = np.random.default_rng(9)
+    pos = rng.random((N, 3)).astype(np.float32) * np.float32(L)
+    pos[: N // 64] = (pos[: N // 64] * np.float32(0.004)) % np.float32(L)          # a corner clump next to three faces
+    vel = rng.normal(0, 1.0, (N, 3)).astype(np.float32)
+    vel[: N // 64] -= 3.0
+    rep = run_pair(64, pos, vel, np.full(N, 1e-4, np.float32), [0.02] * 4, fused=False)
+    assert all(r[0] for r in rep), rep
