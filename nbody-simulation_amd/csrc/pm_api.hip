@@ -79,6 +79,14 @@ int alloc_particles(pm_ctx *c)
     return PM_OK;
 }
 
+// The binning starts from the order before when the drift's estimate of the movers is at most PM_REBIN_SHARE_OF /
+// PM_REBIN_SHARE of the particles.
+#ifndef PM_REBIN_SHARE
+#define PM_REBIN_SHARE 16
+#endif
+#ifndef PM_REBIN_SHARE_OF
+#define PM_REBIN_SHARE_OF 1
+#endif
 // Buffers of the binning that starts from the cell order of the step before (every particle may be a mover).
 int prepare_rebin(pm_ctx *c)
 {
@@ -97,27 +105,13 @@ int ensure_binned(pm_ctx *c)
     if (c->binned) return PM_OK;
     stage_timer t(c, PM_STAGE_BIN);
     HIP_TRY(c, pm_settle_velocities(c));        // src is about to be overwritten
-    // The drift leaves the new keys of the slots (key_in) and an estimate of how many of them differ from the old ones
-    // (key_out, still the sorted keys of this storage order).  Few: the new order is put together from the old one.
-    // The estimate is a step or two old and decides speed only: the kernels count for themselves, and either way gives
-    // the same order.
-    const bool few = c->order_known && c->keys_fresh && c->movers_marked && c->movers_seen && c->n >= PM_REBIN_MIN && c->n < ((int64_t)1 << 30)
-                     && !(c->flags & PM_FLAG_FULL_SORT) && (int64_t)*c->movers_seen * 16 <= c->n;
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
-    c->keys_fresh = false;      // the sort consumes key_in
-    c->movers_marked = false;
-    if (few) {
-        TRY(prepare_rebin(c));
-        HIP_TRY(c, pm_rebin_incremental(c, bits_for(c->g.M)));
-        c->last_incremental = true;
-    } else {
-        c->last_incremental = false;
-        HIP_TRY(c, pm_sort_pairs(c, bits_for(c->g.M)));
-    }
+    TRY(pm_bin_order(c, bits_for(c->g.M)));
     HIP_TRY(c, pm_launch_reorder(c));
     HIP_TRY(c, pm_launch_row_start(c));
     c->binned = true;
     c->order_known = true;
+    c->order_n = c->n;
     // forces / forces64 are indexed by the storage slots of before the reorder: no longer attached to their particles
     c->have_forces = false; c->have_forces64 = false;
     return PM_OK;
@@ -146,6 +140,27 @@ int need_particles(pm_ctx *c)
 
 }  // namespace
 
+// The drift leaves the new keys of the slots (key_in), a bit per slot that changed its key, and an estimate of how many
+// did (the old keys, key_out, are still the sorted keys of this storage order).  Few: the new order is put together from
+// the old one.  The estimate is a step or two old and decides speed only: the kernels count for themselves, and either
+// way gives the same order.
+int pm_bin_order(pm_ctx *c, int bits)
+{
+    const bool few = c->order_known && c->keys_fresh && c->movers_marked && c->movers_seen && c->n >= PM_REBIN_MIN && c->n < ((int64_t)1 << 30)
+                     && !(c->flags & PM_FLAG_FULL_SORT) && (int64_t)*c->movers_seen * PM_REBIN_SHARE <= c->n * PM_REBIN_SHARE_OF;
+    c->keys_fresh = false;      // the binning consumes key_in
+    c->movers_marked = false;
+    if (few) {
+        TRY(prepare_rebin(c));
+        HIP_TRY(c, pm_rebin_incremental(c, bits));
+        c->last_incremental = true;
+    } else {
+        HIP_TRY(c, pm_sort_pairs(c, bits));
+        c->last_incremental = false;
+    }
+    return PM_OK;
+}
+
 static int create_impl(pm_ctx *c)
 {
     const int G = c->g.G;
@@ -160,7 +175,7 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipHostMalloc((void **)&c->units_seen, sizeof(uint32_t), hipHostMallocDefault));
     *c->units_seen = 1;
     HIP_TRY(c, hipHostGetDevicePointer((void **)&c->units_seen_dev, (void *)c->units_seen, 0));
-    if (!c->slab) {
+    {
         HIP_TRY(c, hipHostMalloc((void **)&c->movers_seen, sizeof(uint32_t), hipHostMallocDefault));
         *c->movers_seen = 0xffffffffu;      // nothing known yet: the first binnings sort the whole set
         HIP_TRY(c, hipHostGetDevicePointer((void **)&c->movers_seen_dev, (void *)c->movers_seen, 0));

@@ -110,6 +110,7 @@ struct pm_ctx {
     bool last_incremental = false;      // the last binning started from the order before it
     bool movers_marked = false;         // rb_mask holds the movers of the last drift (for the keys in key_in)
     bool order_known = false;           // key_out holds the sorted keys of the live storage order, row_start its rows
+    int64_t order_n = 0;                // slots of that order (a slab's arrivals are stored behind them until the next binning)
     uint32_t *key_alt = nullptr;        // takes turns with key_out
     uint32_t *rb_ctl = nullptr;         // PM_RB_WORDS control words, then a look-back word per tile
     uint64_t *rb_mask = nullptr;        // per 64 slots: which hold a mover (written by the drift; allocated with the context)
@@ -225,6 +226,8 @@ int pm_generate_param_count(int kind);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);          // key_in -> key_out (sorted), src (storage slot of each sorted entry)
 // the same from the cell order of the step before (key_out, row_start) and the new keys (key_in); key_out / key_alt swap
 hipError_t pm_rebin_incremental(pm_ctx *c, int bits);
+// key_in -> key_out, src, by whichever of the two ways the drift's estimate of its movers favours (pm_api.hip)
+int pm_bin_order(pm_ctx *c, int bits);
 size_t pm_rebin_ctl_bytes(int64_t cap);
 size_t pm_sort_counted_tmp_bytes(int64_t n_max);
 hipError_t pm_sort_pairs_counted(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n_max,

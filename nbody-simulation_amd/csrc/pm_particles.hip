@@ -906,7 +906,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     const cell_t cn = locate(o, g);
     const uint32_t kn = cell_key(cn, g);
     key_next[r] = kn;
-    if constexpr (!SLAB) {
+    {
         // Which particles changed their cell: a bit per slot for the next binning, which may start from this order.
         // And how many, from every 64th workgroup (full ones only), for the host to choose that binning by: one counter
         // update per wave; the wave that reports last hands the estimate over.
@@ -991,8 +991,9 @@ __global__ void k_outbox_offsets(const uint64_t *__restrict__ key, uint32_t coun
 }
 
 // arrivals behind the live set, with their cell keys
+// (movers: the bit per slot that the drift writes for the next binning; an arrival has no place in the old order)
 __global__ void k_append(const pm_migrant *__restrict__ src, pm_prec<float> *__restrict__ P, pm_vrec<float> *__restrict__ V,
-                         uint32_t *__restrict__ key, int64_t at, int64_t count, pm_geom g)
+                         uint32_t *__restrict__ key, int64_t at, int64_t count, pm_geom g, unsigned long long *__restrict__ movers)
 {
     int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= count) return;
@@ -1001,6 +1002,7 @@ __global__ void k_append(const pm_migrant *__restrict__ src, pm_prec<float> *__r
     P[at + r] = p;
     V[at + r] = pm_vrec<float>{m.vx, m.vy, m.vz, m.id};
     key[at + r] = cell_key(locate(p, g), g);
+    if (movers) atomicOr(movers + ((at + r) >> 6), 1ull << ((at + r) & 63));
 }
 
 // per-destination counts as 64-bit integers, counts[d], d < nslabs; then counts[nslabs] = the overflow count, plus
@@ -1179,9 +1181,9 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
     const pm_vrec<TV> *vin = V[c->vcur];
     pm_vrec<TV> *vout = c->v_stale ? V[1 - c->vcur] : V[c->vcur];
     const uint32_t *vmap = c->v_stale ? c->src : nullptr;
-    // the drift of a whole-mesh context also estimates how many particles changed their cell (pm_mover_probe)
+    // the drift also marks the particles that changed their cell and estimates how many they are (pm_mover_probe)
     pm_mover_probe probe{c->mover_count, c->movers_seen_dev, 0u, nullptr};
-    if (integrate && !c->slab && c->mover_count && n >= PM_REBIN_MIN) {
+    if (integrate && c->mover_count && n >= PM_REBIN_MIN) {
         probe.expect = 4u * (uint32_t)((n / BLOCK + 63) / 64);
         probe.mask = c->rb_mask;
         c->movers_marked = c->rb_mask != nullptr;
@@ -1293,7 +1295,17 @@ hipError_t pm_launch_outbox_offsets(pm_ctx *c, uint32_t count, uint32_t *offsets
 hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count)
 {
     if (count == 0) return hipSuccess;
-    k_append<<<grid_for(count), BLOCK, 0, c->stream>>>(src, c->pf[c->cur], c->vf[c->vcur], c->key_in, c->n, count, c->g);
+    if (c->rb_mask) {
+        // the words of the movers' bits that lie wholly behind the slots in use hold nothing yet (the word the first
+        // arrival shares with the last slot in use has the drift's bits, and zeros above them)
+        const int64_t first = (c->n + 63) >> 6, last = (c->n + count + 63) >> 6;
+        if (last > first) {
+            hipError_t e = hipMemsetAsync(c->rb_mask + first, 0, (size_t)(last - first) * sizeof(uint64_t), c->stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    k_append<<<grid_for(count), BLOCK, 0, c->stream>>>(src, c->pf[c->cur], c->vf[c->vcur], c->key_in, c->n, count, c->g,
+                                                      (unsigned long long *)c->rb_mask);
     return hipGetLastError();
 }
 

@@ -139,9 +139,13 @@ __device__ __forceinline__ uint32_t movers_before(const uint64_t *__restrict__ m
 
 // Where sorted mover (k, slot) goes in among the old slots.  The cells of a mesh row are one run of slots (row_start,
 // as the last binning left it), so the search for the new cell's slots stays inside that run.
-__device__ __forceinline__ uint32_t goes_in_at(uint32_t k, uint32_t slot, const uint32_t *__restrict__ key_cur, const uint32_t *__restrict__ row_start, uint32_t G)
+// rows, n_old: the mesh rows and the slots of the old order.  A key past all rows (a particle that has left a slab) goes
+// in behind everything; a slot past n_old (a particle that has just arrived in one) counts as coming from above.
+__device__ __forceinline__ uint32_t goes_in_at(uint32_t k, uint32_t slot, const uint32_t *__restrict__ key_cur, const uint32_t *__restrict__ row_start, uint32_t G,
+                                               uint32_t rows, uint32_t n_old)
 {
     const uint32_t row = k / G;
+    if (row >= rows) return n_old;
     const uint32_t lo = row_start[row], hi = row_start[row + 1];
     const uint32_t first = lower_bound(key_cur, lo, hi, k);
     // from a cell below: before the cell's first slot; from a cell above: behind its last one
@@ -156,18 +160,18 @@ k_place_movers(const uint32_t *__restrict__ mk, const uint32_t *__restrict__ mi,
                const uint32_t *__restrict__ key_cur, const uint32_t *__restrict__ row_start, uint32_t G,
                const uint64_t *__restrict__ mask, const uint32_t *__restrict__ before,
                uint32_t *__restrict__ src, uint32_t *__restrict__ key_sorted, uint32_t *__restrict__ at,
-               uint32_t *__restrict__ tile_first, uint32_t tiles)
+               uint32_t *__restrict__ tile_first, uint32_t tiles, uint32_t rows, uint32_t n_old)
 {
     const uint32_t m = ctl[PM_RB_MOVERS];
     for (uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256u) {
         const uint32_t k = mk[j], slot = mi[j];
-        const uint32_t t = goes_in_at(k, slot, key_cur, row_start, G);
+        const uint32_t t = goes_in_at(k, slot, key_cur, row_start, G, rows, n_old);
         const uint32_t pos = (uint32_t)j + t - movers_before(mask, before, t);
         src[pos] = slot;
         key_sorted[pos] = k;
         at[j] = t;
         // tiles whose first slot lies in (t_(j-1), t_j] have j movers before them; behind the last mover, all m
-        const uint32_t from = j == 0 ? 0u : goes_in_at(mk[j - 1], mi[j - 1], key_cur, row_start, G) / (uint32_t)RB_TILE + 1u;
+        const uint32_t from = j == 0 ? 0u : goes_in_at(mk[j - 1], mi[j - 1], key_cur, row_start, G, rows, n_old) / (uint32_t)RB_TILE + 1u;
         for (uint32_t T = from; T <= t / (uint32_t)RB_TILE && T <= tiles; ++T) tile_first[T] = (uint32_t)j;
         if (j + 1 == m)
             for (uint32_t T = t / (uint32_t)RB_TILE + 1u; T <= tiles; ++T) tile_first[T] = m;
@@ -224,8 +228,10 @@ size_t pm_rebin_ctl_bytes(int64_t cap)
     return (PM_RB_WORDS + 2 * tiles + 2) * sizeof(uint32_t);         // control words, look-back words, tile_first
 }
 
-// key_out (the keys of the storage order, sorted), key_in (the new keys of the same slots), rb_mask (where the two differ:
-// written by the drift), row_start (of the storage order) -> src and key_alt, as pm_sort_pairs would leave src and key_out.  Returns with key_out and key_alt exchanged.
+// key_out (the sorted keys of the old order's order_n slots), key_in (the new keys of the n slots now in use: the same
+// slots, and behind them the arrivals of a slab), rb_mask (where the two differ, and the arrivals: written by the drift
+// and by pm_launch_append), row_start (of the old order) -> src and key_alt, as pm_sort_pairs would leave src and
+// key_out.  Returns with key_out and key_alt exchanged.
 hipError_t pm_rebin_incremental(pm_ctx *c, int bits)
 {
     const uint32_t n = (uint32_t)c->n;
@@ -242,7 +248,7 @@ hipError_t pm_rebin_incremental(pm_ctx *c, int bits)
                               c->device, c->stream);
     if (e != hipSuccess) return e;
     k_place_movers<<<1024, 256, 0, c->stream>>>(c->rb_key[1], c->rb_slot[1], ctl, c->key_out, c->row_start, (uint32_t)c->g.G, c->rb_mask, c->rb_before, c->src,
-                                                c->key_alt, c->rb_at, tile_first, tiles);
+                                                c->key_alt, c->rb_at, tile_first, tiles, (uint32_t)c->g.Gs * (uint32_t)c->g.G, (uint32_t)c->order_n);
     k_place_stayers<<<tiles, RB_BLOCK, 0, c->stream>>>(c->key_in, n, c->rb_mask, c->rb_before, c->rb_at, tile_first, c->src, c->key_alt);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     uint32_t *k = c->key_out; c->key_out = c->key_alt; c->key_alt = k;

@@ -114,14 +114,15 @@ int ensure_binned(pm_ctx *c)
     if (c->binned) return PM_OK;
     HIP_TRY(c, pm_settle_velocities(c));
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
-    c->keys_fresh = false;
     // one key more than the slab has cells: "not mine" -- which a slab that is the whole mesh never hands out
-    HIP_TRY(c, pm_sort_pairs(c, bits_for((int64_t)c->g.Gs * c->g.G * c->g.G + (c->g.Gs != c->g.G ? 1 : 0))));
+    TRY(pm_bin_order(c, bits_for((int64_t)c->g.Gs * c->g.G * c->g.G + (c->g.Gs != c->g.G ? 1 : 0))));
     HIP_TRY(c, pm_launch_reorder(c));
     HIP_TRY(c, pm_launch_row_start(c));
     c->n -= c->leaving;         // they carry the last key: the tail of the cell order
     c->leaving = 0;
     c->binned = true;
+    c->order_known = true;
+    c->order_n = c->n;
     c->have_forces = false; c->have_forces64 = false;      // indexed by the storage slots of before the reorder
     return PM_OK;
 }

@@ -41,7 +41,8 @@ def slab_of(positions, grid_size, box_size, world):
 class HipSlabEngine:
     """Local stages of one slab on one GPU through libpm.so."""
 
-    def __init__(self, grid_size, box_size, plane0, nplanes, capacity, device_index=0, rocfft_only=False):
+    def __init__(self, grid_size, box_size, plane0, nplanes, capacity, device_index=0, rocfft_only=False, full_sort=False):
+        """full_sort: PM_FLAG_FULL_SORT (every binning sorts the whole slab; for comparisons)"""
         self.lib = _lib.load()
         self.G, self.L, self.i0, self.Gs = int(grid_size), float(box_size), int(plane0), int(nplanes)
         self.world = self.G // self.Gs
@@ -50,7 +51,7 @@ class HipSlabEngine:
         self.cap = int(capacity)
         # FLAG_FUSED_GRADIENT on a slab: where the hand-written transforms apply, the deposit writes its planes already
         # transformed along z (no density mesh); elsewhere the flag changes nothing
-        flags = _lib.FLAG_FUSED_GRADIENT | (_lib.FLAG_ROCFFT_ONLY if rocfft_only else 0)
+        flags = _lib.FLAG_FUSED_GRADIENT | (_lib.FLAG_ROCFFT_ONLY if rocfft_only else 0) | (_lib.FLAG_FULL_SORT if full_sort else 0)
         self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, flags, self.i0, self.Gs)
         if not self.ctx:
             raise _lib.PMError("pm_create_slab failed: " + (self.lib.pm_last_error(None) or b"?").decode())
@@ -69,6 +70,14 @@ class HipSlabEngine:
         if self.ctx:
             self.lib.pm_destroy(self.ctx)
             self.ctx = None
+
+    def last_binning(self):
+        """(from the order before?, movers) of the slab's last binning (pm_last_binning)"""
+        movers = ctypes.c_int64(0)
+        rc = self.lib.pm_last_binning(self.ctx, ctypes.byref(movers))
+        if rc < 0:
+            self._check(rc)
+        return bool(rc), int(movers.value)
 
     def _check(self, rc):
         _lib.check(self.ctx, rc)

@@ -89,3 +89,61 @@ def test_staged_pipeline_and_wrapping_movers():
     vel[: N // 64] -= 3.0
     rep = run_pair(64, pos, vel, np.full(N, 1e-4, np.float32), [0.02] * 4, fused=False)
     assert all(r[0] for r in rep), rep
+
+
+def test_slabs_with_arrivals_and_leavers():
+    """Two slabs of a 128^3 mesh as threads on the one GPU, 2^21 particles each: particles change slabs every step (they
+    leave with the key past all cells and arrive behind the slots in use), and the slabs that start from the order before
+    end every step with the same particles, positions and velocities, bit for bit, as slabs that sort everything."""
+    import threading
+    from pm.distributed import SlabSimulation, ThreadComm, HipSlabEngine, slab_of
+    G, world, n = 128, 2, 2 * N
+    rng = np.random.default_rng(21)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    vel = rng.normal(0, 2.0, (n, 3)).astype(np.float32)
+    mass = np.full(n, 1e-4, np.float32)
+    ids = np.arange(n, dtype=np.uint32)
+    owner = slab_of(pos, G, L, world)
+    lock = threading.Lock()
+
+    def run(full_sort):
+        comms = ThreadComm.make(world)
+        results, reports, errors = [None] * world, [None] * world, []
+
+        def rank(r):
+            try:
+                mine = owner == r
+                cap = int(mine.sum() * 1.2)
+                with lock:
+                    eng = HipSlabEngine(G, L, r * (G // world), G // world, cap, 0, full_sort=full_sort)
+                    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids[mine], device_index=0, capacity=cap, comm=comms[r], engine=eng)
+                out, rep = [], []
+                for _ in range(4):
+                    sim.step(0.005)
+                    out.append(sim.particles())
+                    rep.append(eng.last_binning())
+                sim.synchronize()
+                sim.close()
+                results[r], reports[r] = out, rep
+            except BaseException as e:                  # a thread that dies must not leave the other at a barrier
+                errors.append(e)
+                comms[r]._s.barrier.abort()
+
+        threads = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(600)
+        assert not errors, errors
+        return results, reports
+
+    inc, rep_inc = run(False)
+    full, rep_full = run(True)
+    for r in range(world):
+        assert all(not x[0] for x in rep_full[r]), rep_full[r]
+        assert all(x[0] and x[1] > 0 for x in rep_inc[r]), rep_inc[r]
+        moved = 0
+        for (ia, xa, va), (ib, xb, vb) in zip(inc[r], full[r]):
+            assert np.array_equal(ia, ib) and np.array_equal(xa, xb) and np.array_equal(va, vb)
+            moved += int((owner[ia] != r).sum())
+        assert moved > 0                                # particles did change slabs

@@ -26,6 +26,9 @@ ap.add_argument("--rocfft-only", action="store_true")
 ap.add_argument("--workload", default="uniform", help="uniform: --n particles inside slab 0; or a workload of bench.py (two_galaxy, disk): --n is then the WHOLE "
                                                      "set, and --rank picks the slab whose share is timed (-1: every slab in turn)")
 ap.add_argument("--rank", type=int, default=-1)
+ap.add_argument("--quiet-set", action="store_true", help="uniform workload: light particles (1e-6) with the velocities of bench.py's uniform set "
+                                                        "(sigma 10), so that few particles change their cell per step")
+ap.add_argument("--full-sort", action="store_true", help="PM_FLAG_FULL_SORT: every binning sorts the whole slab")
 args = ap.parse_args()
 
 import torch  # noqa: E402
@@ -39,7 +42,7 @@ PH = ("deposit", "fft_zy", "solve_x", "ifft_yz", "gather_kick_drift", "migration
 
 def one_slab(rank, pos, vel, mass, ids):
     n = len(pos)
-    e = HipSlabEngine(G, L, rank * Gs, Gs, int(n * 1.1) + 4096, 0, rocfft_only=args.rocfft_only)
+    e = HipSlabEngine(G, L, rank * Gs, Gs, int(n * 1.1) + 4096, 0, rocfft_only=args.rocfft_only, full_sort=args.full_sort)
     e.set_particles(pos, vel, mass, ids)
     acc = dict.fromkeys(PH, 0.0)
 
@@ -83,7 +86,7 @@ def one_slab(rank, pos, vel, mass, ids):
     total = sum(out.values())
     m_local = G * G * Gs
     line = {"grid": G, "slabs": P, "slab": rank, "planes": Gs, "particles_in_slab_at_start": n, "hand_written_transforms": bool(e.spectral),
-            "phases_ms": out, "local_ms_per_step": round(total, 3),
+            "phases_ms": out, "local_ms_per_step": round(total, 3), "last_binning_from_order_before_and_movers": e.last_binning(),
             "local_algorithmic_GB": round((64 * n + 80 * m_local) / 1e9, 2),
             "local_frac_of_8TBps": round((64 * n + 80 * m_local) / (total * 1e-3) / 8e12, 3)}
     print(json.dumps(line), flush=True)
@@ -97,7 +100,10 @@ if args.workload == "uniform":
     pos = np.empty((n, 3), np.float32)
     pos[:, 0] = (rng.random(n) * (L / P) * 0.998 + 0.001 * L / P).astype(np.float32)
     pos[:, 1:] = (rng.random((n, 2)) * L).astype(np.float32)
-    one_slab(0, pos, np.zeros((n, 3), np.float32), np.ones(n, np.float32), np.arange(n, dtype=np.uint32))
+    if args.quiet_set:
+        one_slab(0, pos, rng.normal(0, 10, (n, 3)).astype(np.float32), np.full(n, 1e-6, np.float32), np.arange(n, dtype=np.uint32))
+    else:
+        one_slab(0, pos, np.zeros((n, 3), np.float32), np.ones(n, np.float32), np.arange(n, dtype=np.uint32))
 else:
     # a slab's share of a whole set, with the velocities set to zero so that nobody leaves (the halos are the slab's own
     # planes: a particle that left would be handed to a neighbour that is not there)
