@@ -39,14 +39,16 @@ __device__ __forceinline__ uint32_t lower_bound(P a, uint32_t lo, uint32_t hi, u
     return lo;
 }
 
-// The drift has left a bit per slot (mask[g]: which of slots 64 g .. 64 g + 63 hold a mover).  A tile is RS_TILE such
-// words: before[g] = movers in the slots before 64 g, through a look-back chain over the tiles, and (mk, mi) = the
-// movers' new keys and slots, compacted in slot order.  ctl (cleared by the caller): PM_RB_TICKET hands out the tiles;
-// the last tile writes the number of movers.  states: one look-back word per tile, cleared by the caller.
+// The drift has left a bit per slot of the old order's n_old slots: which hold a mover.  A thread takes four words of 64
+// slots, marks the slots from n_old on (a slab's arrivals, which have no place in the old order) and writes them back:
+// mask[g] = which of slots 64 g .. 64 g + 63 hold a mover.  A tile is RS_TILE such words: before[g] = movers in the
+// slots before 64 g, through a look-back chain over the tiles, and (mk, mi) = the movers' new keys and slots, compacted
+// in slot order.  ctl (cleared by the caller): PM_RB_TICKET hands out the tiles; the last tile writes the number of
+// movers.  states: one look-back word per tile, cleared by the caller.
 constexpr int RS_ITEMS = 4, RS_TILE = RB_BLOCK * RS_ITEMS;
 
 __global__ void __launch_bounds__(RB_BLOCK)
-k_scan_movers(const uint64_t *mask_in, const uint32_t *__restrict__ key_new, uint32_t n, uint64_t *mask /* the same array: one word past the last is written */,
+k_scan_movers(uint64_t *__restrict__ mask, const uint32_t *__restrict__ key_new, uint32_t n_old, uint32_t n,
               uint32_t *__restrict__ before, uint32_t *__restrict__ mk, uint32_t *__restrict__ mi,
               uint32_t *__restrict__ states, uint32_t *__restrict__ ctl)
 {
@@ -56,25 +58,30 @@ k_scan_movers(const uint64_t *mask_in, const uint32_t *__restrict__ key_new, uin
     __syncthreads();
     const uint32_t tile = misc[0], tiles = gridDim.x;
     const uint32_t groups = (n + 63u) >> 6;
-    const uint32_t base = tile * (uint32_t)RS_TILE + (uint32_t)w * (64u * RS_ITEMS);       // first word of this wave
+    const uint32_t g0 = tile * (uint32_t)RS_TILE + (uint32_t)t * RS_ITEMS;      // this thread's first word
     uint64_t bits[RS_ITEMS];
-    uint32_t excl[RS_ITEMS];                            // movers in the wave's words before this one
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) bits[i] = g0 + i < groups ? mask[g0 + i] : 0ull;
     uint32_t mine = 0;
+    uint32_t cnt[RS_ITEMS];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
-        const uint32_t g = base + 64u * i + (uint32_t)lane;
-        bits[i] = g < groups ? mask_in[g] : 0ull;
-        const uint32_t c = (uint32_t)__popcll(bits[i]);
-        uint32_t incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        excl[i] = mine + incl - c;
-        mine += __shfl(incl, 63);
+        const uint64_t first = (uint64_t)(g0 + i) << 6;            // the word's first slot
+        // slots from n_old on are movers, slots from n on are no slots
+        if (first + 64u > n_old) bits[i] |= first >= n_old ? ~0ull : ~0ull << (n_old - first);
+        if (first + 64u > n) bits[i] &= first >= n ? 0ull : ~(~0ull << (n - first));
+        if (g0 + i < groups) mask[g0 + i] = bits[i];
+        cnt[i] = (uint32_t)__popcll(bits[i]);
+        mine += cnt[i];
     }
-    if (lane == 0) wsum[w] = mine;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const uint32_t in_wave = incl - mine;               // movers in the wave's words before this thread's
+    if (lane == 63) wsum[w] = incl;
     __syncthreads();
     uint32_t in_tile = 0, total = 0;                    // movers of the tile before this wave's words; of the whole tile
     for (int q = 0; q < RB_WAVES; ++q) { const uint32_t c = wsum[q]; if (q < w) in_tile += c; total += c; }
@@ -115,12 +122,11 @@ k_scan_movers(const uint64_t *mask_in, const uint32_t *__restrict__ key_new, uin
         }
     }
     __syncthreads();
-    const uint32_t first = misc[1] + in_tile;
+    uint32_t at = misc[1] + in_tile + in_wave;
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
-        const uint32_t g = base + 64u * i + (uint32_t)lane;
-        if (g >= groups) continue;
-        uint32_t at = first + excl[i];
+        const uint32_t g = g0 + (uint32_t)i;
+        if (g >= groups) break;
         before[g] = at;
         for (uint64_t b = bits[i]; b != 0ull; b &= b - 1ull, ++at) {       // (mostly no turn at all)
             const uint32_t slot = (g << 6) + (uint32_t)(__ffsll((long long)b) - 1);
@@ -229,8 +235,7 @@ size_t pm_rebin_ctl_bytes(int64_t cap)
 }
 
 // key_out (the sorted keys of the old order's order_n slots), key_in (the new keys of the n slots now in use: the same
-// slots, and behind them the arrivals of a slab), rb_mask (where the two differ, and the arrivals: written by the drift
-// and by pm_launch_append), row_start (of the old order) -> src and key_alt, as pm_sort_pairs would leave src and
+// slots, and behind them the arrivals of a slab), rb_mask (where the two differ: written by the drift), row_start (of the old order) -> src and key_alt, as pm_sort_pairs would leave src and
 // key_out.  Returns with key_out and key_alt exchanged.
 hipError_t pm_rebin_incremental(pm_ctx *c, int bits)
 {
@@ -241,7 +246,8 @@ hipError_t pm_rebin_incremental(pm_ctx *c, int bits)
     hipError_t e = hipMemsetAsync(c->rb_ctl, 0, (PM_RB_WORDS + (size_t)stiles + tiles + 1) * sizeof(uint32_t), c->stream);
     if (e != hipSuccess) return e;
     uint32_t *ctl = c->rb_ctl, *states = c->rb_ctl + PM_RB_WORDS, *tile_first = states + stiles;
-    k_scan_movers<<<stiles, RB_BLOCK, 0, c->stream>>>(c->rb_mask, c->key_in, n, c->rb_mask, c->rb_before, c->rb_key[0], c->rb_slot[0], states, ctl);
+    k_scan_movers<<<stiles, RB_BLOCK, 0, c->stream>>>(c->rb_mask, c->key_in, (uint32_t)c->order_n, n, c->rb_before, c->rb_key[0],
+                                                      c->rb_slot[0], states, ctl);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // (the workspace of the sort of the whole set, which does not run in a binning that takes this path)
     e = pm_sort_pairs_counted(c->sort_tmp, c->sort_tmp_bytes, c->rb_key[0], c->rb_key[1], c->rb_slot[0], c->rb_slot[1], n, ctl + PM_RB_MOVERS, bits,
