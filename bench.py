@@ -319,6 +319,7 @@ def main():
     # how steady the number is: the same block of K steps a few more times (the particles keep moving: not the same steps)
     blocks = [elapsed / args.steps * 1e3] + [timed_block() / args.steps * 1e3 for _ in range(max(args.repeats, 0) if world == 1 else 0)]
 
+    binning = sim.last_binning()
     sim.close()
     # beside the headline: the uniform particle set of the same size on the same mesh (one GPU, default workload only)
     also = None
@@ -375,6 +376,9 @@ def main():
                               "unit": "GB/s", "frac": b_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                               "pipeline_bytes_per_step": b_pipe, "pipeline_frac": b_pipe / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "ms_per_step_blocks": [round(x, 4) for x in blocks], "ms_per_step_median": float(np.median(blocks)),
+            # how the last step's particles were brought into cell order: put together from the order before (then with the
+            # exact number of particles that had changed their cell), or all sorted (then with the drift's estimate of it)
+            "last_binning": {"from_order_before": binning[0], "movers": binning[1]},
             "stage_ms": per,
             "kernel_ms": {k: round(v, 5) for k, v in kper.items()},
             # every timed stage against the same peak, with the bytes the stage cannot avoid in the pipeline that ran; the

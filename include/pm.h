@@ -180,7 +180,8 @@ int pm_set_mesh(pm_ctx *ctx, int which, const float *in /* G*G*G */);
 int pm_get_cell_keys(pm_ctx *ctx, int64_t *keys, int64_t *perm);
 /* How the last binning got its order (a diagnostic of this engine; the reference has no cell order).  Returns 1 if it
  * was put together from the order of the step before, with *movers = the particles that had changed their cell; 0 if
- * the whole set was sorted (*movers = 0); negative on error.  Synchronises. */
+ * the whole set was sorted, with *movers = the latest estimate of them that a drift has sent to the host (a sample
+ * scaled up; -1 if there is none yet); negative on error.  Synchronises. */
 int pm_last_binning(pm_ctx *ctx, int64_t *movers);
 
 /* compute_kinetic_energy(velocities, masses) and compute_potential_energy(positions, masses,

@@ -752,7 +752,12 @@ int pm_last_binning(pm_ctx *c, int64_t *movers)
 {
     if (!c || !movers) return PM_EINVAL;
     *movers = 0;
-    if (!c->last_incremental) return 0;
+    if (!c->last_incremental) {
+        // the drift's estimate, as the host last saw it (what the choice was made by, or a newer one)
+        const uint32_t seen = c->movers_seen ? *c->movers_seen : 0xffffffffu;
+        *movers = seen == 0xffffffffu ? -1 : (int64_t)seen;
+        return 0;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     uint32_t ctl[PM_RB_WORDS];
     HIP_TRY(c, hipMemcpyAsync(ctl, c->rb_ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
