@@ -1186,8 +1186,11 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
     pm_mover_probe probe{c->mover_count, c->movers_seen_dev, 0u, nullptr};
     if (integrate && c->mover_count && n >= PM_REBIN_MIN) {
         probe.expect = 4u * (uint32_t)((n / BLOCK + 63) / 64);
-        probe.mask = c->rb_mask;
-        c->movers_marked = c->rb_mask != nullptr;
+        // the bits are for a binning that starts from this order: not written while the estimates say that far too many
+        // particles move for that (a set that calms down is marked from the step after the estimate says so)
+        const uint32_t seen = c->movers_seen ? *c->movers_seen : 0u;
+        probe.mask = (seen == 0xffffffffu || (int64_t)seen * 4 <= n) ? c->rb_mask : nullptr;
+        c->movers_marked = probe.mask != nullptr;
     }
     auto launch = [&](auto mapped) {
         constexpr bool M = decltype(mapped)::value;
