@@ -369,6 +369,8 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     c->pos_in_f64 = c->pos_f64 = (pos_dtype == PM_F64);
     c->vel_f64 = (vel_dtype == PM_F64);
     TRY(alloc_particles(c));
+    // (a set large enough to be binned from the order before: its buffers now, not inside the first step that wants them)
+    if (n >= PM_REBIN_MIN && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
     c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
     size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
     if (n > 0) {
@@ -406,6 +408,8 @@ int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *par
     c->pos_in_f64 = c->pos_f64 = false;
     c->vel_f64 = false;
     TRY(alloc_particles(c));
+    // (a set large enough to be binned from the order before: its buffers now, not inside the first step that wants them)
+    if (n >= PM_REBIN_MIN && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
     c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
     HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
