@@ -231,7 +231,7 @@ k_place_stayers(const uint32_t *__restrict__ key_new, uint32_t n, const uint64_t
 size_t pm_rebin_ctl_bytes(int64_t cap)
 {
     const size_t tiles = ((size_t)cap + RB_TILE - 1) / RB_TILE;
-    return (PM_RB_WORDS + 2 * tiles + 2) * sizeof(uint32_t);         // control words, look-back words, tile_first
+    return (PM_RB_WORDS + 2 * tiles + 2 + 4) * sizeof(uint32_t);     // control words, look-back words, tile_first (cleared in 16-byte pieces)
 }
 
 // key_out (the sorted keys of the old order's order_n slots), key_in (the new keys of the n slots now in use: the same
@@ -243,7 +243,7 @@ hipError_t pm_rebin_incremental(pm_ctx *c, int bits)
     if (n == 0) return hipSuccess;
     const uint32_t tiles = (n + RB_TILE - 1) / RB_TILE;                 // of slots (k_place_stayers)
     const uint32_t groups = (n + 63u) >> 6, stiles = (groups + RS_TILE - 1) / RS_TILE;      // of mask words (k_scan_movers)
-    hipError_t e = hipMemsetAsync(c->rb_ctl, 0, (PM_RB_WORDS + (size_t)stiles + tiles + 1) * sizeof(uint32_t), c->stream);
+    hipError_t e = pm_launch_clear(c->rb_ctl, ((PM_RB_WORDS + (size_t)stiles + tiles + 1) * sizeof(uint32_t) + 15) / 16 * 16, c->stream);
     if (e != hipSuccess) return e;
     uint32_t *ctl = c->rb_ctl, *states = c->rb_ctl + PM_RB_WORDS, *tile_first = states + stiles;
     k_scan_movers<<<stiles, RB_BLOCK, 0, c->stream>>>(c->rb_mask, c->key_in, (uint32_t)c->order_n, n, c->rb_before, c->rb_key[0],

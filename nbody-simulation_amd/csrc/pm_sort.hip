@@ -352,6 +352,26 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
   }
 }
 
+__global__ void k_clear(uint4 *__restrict__ p, size_t n)
+{
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) p[q] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+}  // namespace
+
+// Zeroes `bytes` bytes (a multiple of 16, 16-byte aligned) with a kernel of this library: the runtime's fill command does
+// the same work but costs the stream 5 us more per sort.
+hipError_t pm_launch_clear(void *p, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    if (bytes % 16 != 0 || ((uintptr_t)p & 15) != 0) return hipMemsetAsync(p, 0, bytes, s);
+    const size_t n = bytes / 16, want = (n + 255) / 256;
+    k_clear<<<(unsigned)(want < 2048 ? want : 2048), 256, 0, s>>>((uint4 *)p, n);
+    return hipGetLastError();
+}
+
+namespace {
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 
 constexpr size_t SORT_ALIGN = 256;
@@ -441,7 +461,7 @@ hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const 
     S *states = (S *)(w + p.states);
     K *ktmp = (K *)(w + p.keys_tmp);
     uint32_t *vtmp = (uint32_t *)(w + p.values_tmp);
-    hipError_t e = hipMemsetAsync(w, 0, p.cleared, s);
+    hipError_t e = pm_launch_clear(w, p.cleared, s);
     if (e != hipSuccess) return e;
     const size_t per_count = (size_t)PM_COUNT_BLOCK * COUNT_ITEMS;
     const size_t want = (n + per_count - 1) / per_count;
