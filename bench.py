@@ -140,7 +140,7 @@ def fused_stage_bytes(n, m):
 
 
 # kernels that make up each timed stage (substrings of the names rocprofv3 reports)
-STAGE_KERNELS = {"bin": ["k_radix_pass", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start", "k_cell_keys", "fillBuffer"],
+STAGE_KERNELS = {"bin": ["k_radix_pass", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start", "k_cell_keys", "fillBuffer", "k_clear"],
                  "deposit": ["k_deposit_rows", "k_deposit_units", "k_sum_units"],
                  "fft_fwd": ["k_row_r2c", "k_col_fft<512, -1, false>"], "green": ["k_col_fft<512, -1, true>", "k_green"],
                  "fft_inv": ["k_col_fft<512, 1, false>", "k_row_c2r"], "gradient": ["k_gradient"], "gather": ["k_gather"]}
