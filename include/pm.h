@@ -56,7 +56,8 @@ enum {
     PM_FLAG_FULL_SORT = 64u   /* the particles are brought into cell order by sorting all of them every time.  Without it
                                  a step in which few particles changed their cell (the drift counts them) puts the new
                                  order together from the old one -- the movers are sorted and merged in -- which gives
-                                 the same order and is faster; the flag is there to compare the two */
+                                 the same order and is faster (for sets of 2^20 particles and more; the environment variable
+                                 PM_REBIN_MIN, read by pm_create, sets another bound); the flag is there to compare the two */
 };
 
 /* stages reported by pm_stage_times, in this order */

@@ -1,6 +1,8 @@
 // C ABI of libpm.so: context management, host copies, stage sequencing.
 #include "pm_internal.hpp"
 
+#include <cstdlib>
+
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -146,7 +148,7 @@ int need_particles(pm_ctx *c)
 // way gives the same order.
 int pm_bin_order(pm_ctx *c, int bits)
 {
-    const bool few = c->order_known && c->keys_fresh && c->movers_marked && c->movers_seen && c->n >= PM_REBIN_MIN && c->n < ((int64_t)1 << 30)
+    const bool few = c->order_known && c->keys_fresh && c->movers_marked && c->movers_seen && c->n >= c->rebin_min && c->n < ((int64_t)1 << 30)
                      && !(c->flags & PM_FLAG_FULL_SORT) && (int64_t)*c->movers_seen * PM_REBIN_SHARE <= c->n * PM_REBIN_SHARE_OF;
     c->keys_fresh = false;      // the binning consumes key_in
     c->movers_marked = false;
@@ -269,6 +271,13 @@ pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int
     c->g.i0 = plane0; c->g.Gs = nplanes; c->g.Gd = slab ? nplanes + 1 : grid_size; c->g.lo = slab ? 1 : 0;
     c->g.sb = (c->fft_custom && !slab) ? pm_fft_spectrum_interleave(grid_size) : 0;
     c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
+    // (for tests: sets smaller than a million particles gain nothing from it, but every test of the path can then run on
+    // the order put together from the order before)
+    if (const char *v = std::getenv("PM_REBIN_MIN")) {
+        char *end = nullptr;
+        const long long m = std::strtoll(v, &end, 10);
+        if (end != v && m >= 1) c->rebin_min = (int64_t)m;
+    }
     if (create_impl(c) != PM_OK) {
         g_create_error = c->err;
         pm_destroy(c);
@@ -370,7 +379,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     c->vel_f64 = (vel_dtype == PM_F64);
     TRY(alloc_particles(c));
     // (a set large enough to be binned from the order before: its buffers now, not inside the first step that wants them)
-    if (n >= PM_REBIN_MIN && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
+    if (n >= c->rebin_min && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
     c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
     size_t ps = c->pos_f64 ? 8 : 4, vs = c->vel_f64 ? 8 : 4;
     if (n > 0) {
@@ -409,7 +418,7 @@ int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *par
     c->vel_f64 = false;
     TRY(alloc_particles(c));
     // (a set large enough to be binned from the order before: its buffers now, not inside the first step that wants them)
-    if (n >= PM_REBIN_MIN && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
+    if (n >= c->rebin_min && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
     c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
     HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

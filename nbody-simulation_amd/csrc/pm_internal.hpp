@@ -58,13 +58,13 @@ template <> struct alignas(16) pm_vrec<double> { double x, y, z; uint32_t id; ui
 // of the sort that follows)
 enum { PM_RB_TICKET = 0, PM_RB_MOVERS = 1, PM_RB_WORDS = 8 };
 
-constexpr int64_t PM_REBIN_MIN = 1 << 20;       // particle sets below this are always sorted whole
+constexpr int64_t PM_REBIN_MIN = 1 << 20;       // particle sets below this are always sorted whole (pm_ctx::rebin_min: the environment may say otherwise)
 // What the drift reports about the particles that changed their cell.  mask (may be null): a bit per storage slot, in
 // words of 64 slots, set where the particle's new cell key differs from its old one.  A sample of the workgroups also
 // counts them for the host: *count holds the waves that have reported (upper half) and the movers they saw (lower
 // half); the last of `expect` waves writes the estimate for the whole set to *seen (pinned host memory) and clears the
 // word.  expect == 0: nothing is counted.
-struct pm_mover_probe { unsigned long long *count; volatile uint32_t *seen; uint32_t expect; uint64_t *mask; };
+struct pm_mover_probe { unsigned long long *count; volatile uint32_t *seen; uint32_t expect; uint64_t *mask; uint32_t every; };
 
 struct pm_ctx {
     pm_geom g{};
@@ -107,6 +107,7 @@ struct pm_ctx {
     // binning scratch
     uint32_t *key_in = nullptr, *key_out = nullptr, *src = nullptr;
     // binning from the cell order of the step before (pm_rebin.hip; buffers allocated on first use)
+    int64_t rebin_min = PM_REBIN_MIN;   // PM_REBIN_MIN, or what the environment variable of that name said when the context was made
     bool last_incremental = false;      // the last binning started from the order before it
     bool movers_marked = false;         // rb_mask holds the movers of the last drift (for the keys in key_in)
     bool order_known = false;           // key_out holds the sorted keys of the live storage order, row_start its rows

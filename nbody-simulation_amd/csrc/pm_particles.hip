@@ -911,12 +911,12 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     key_next[r] = kn;
     {
         // Which particles changed their cell: a bit per slot for the next binning, which may start from this order.
-        // And how many, from every 64th workgroup (full ones only), for the host to choose that binning by: one counter
+        // And how many, from a sample of the workgroups (full ones only), for the host to choose that binning by: one counter
         // update per wave; the wave that reports last hands the estimate over.
         const unsigned long long moved = __ballot(kn != k_old);
         if (probe.mask != nullptr && lane_id() == 0) probe.mask[r >> 6] = moved;
         const uint32_t blk = (uint32_t)(r / BLOCK);
-        if (probe.expect != 0u && (blk & 63u) == 0u && (int64_t)(blk + 1u) * BLOCK <= n) {
+        if (probe.expect != 0u && (blk & (probe.every - 1u)) == 0u && (int64_t)(blk + 1u) * BLOCK <= n) {
             if (lane_id() == 0) {
                 // one word holds both the waves that have reported (upper half) and their movers (lower half): the
                 // wave that completes the count has the sum in hand, and no fence is needed to order two words
@@ -925,7 +925,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
                 if ((uint32_t)(all >> 32) == probe.expect) {
                     atomicExch(probe.count, 0ull);
                     const uint32_t seen = (uint32_t)all;
-                    *probe.seen = seen > 0x03ffffffu ? 0xffffffffu : seen * 64u;
+                    *probe.seen = (unsigned long long)seen * probe.every > 0xfffffffeull ? 0xfffffffeu : seen * probe.every;
                 }
             }
         }
@@ -1183,9 +1183,12 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
     pm_vrec<TV> *vout = c->v_stale ? V[1 - c->vcur] : V[c->vcur];
     const uint32_t *vmap = c->v_stale ? c->src : nullptr;
     // the drift also marks the particles that changed their cell and estimates how many they are (pm_mover_probe)
-    pm_mover_probe probe{c->mover_count, c->movers_seen_dev, 0u, nullptr};
-    if (integrate && c->mover_count && n >= PM_REBIN_MIN) {
-        probe.expect = 4u * (uint32_t)((n / BLOCK + 63) / 64);
+    pm_mover_probe probe{c->mover_count, c->movers_seen_dev, 0u, nullptr, 64u};
+    if (integrate && c->mover_count && n >= c->rebin_min) {
+        // the sample: every 64th workgroup of a large set, more of a small one (about a thousand workgroups where there are as many)
+        const int64_t full = n / BLOCK;
+        while (probe.every > 1u && full / probe.every < 1024) probe.every >>= 1;
+        probe.expect = 4u * (uint32_t)((full + probe.every - 1) / probe.every);
         // the bits are for a binning that starts from this order: not written while the estimates say that far too many
         // particles move for that (a set that calms down is marked from the step after the estimate says so)
         const uint32_t seen = c->movers_seen ? *c->movers_seen : 0u;

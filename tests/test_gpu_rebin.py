@@ -62,9 +62,9 @@ def test_few_movers_same_order(G, clumped):
 
 
 def test_nearly_everyone_moves():
-    """The drift estimates its movers from every 64th workgroup of 256 slots.  Here exactly those slots hold particles
+    """The drift estimates its movers from a sample of its workgroups of 256 slots (of this set: every 8th).  Here exactly those slots hold particles
     at rest and all others move a cell or more: the estimate says `none`, the binning starts from the old order, finds
-    63 of 64 particles moved -- and still arrives at the order the sort of everything gives."""
+    7 of 8 particles moved -- and still arrives at the order the sort of everything gives."""
     G = 128
     pos, _, _ = make(5, 0.0)
     with pm.Simulation(G, L, pos, np.zeros((N, 3), np.float32), np.ones(N, np.float32)) as probe:
@@ -72,7 +72,7 @@ def test_nearly_everyone_moves():
         _, perm = probe.cell_keys()                      # perm[r]: the particle stored at slot r after the first binning
     slot = np.empty(N, np.int64)
     slot[perm] = np.arange(N)
-    sampled = (slot // 256) % 64 == 0
+    sampled = (slot // 256) % 8 == 0                # (2^21 particles: 8192 workgroups, every 8th makes 1024)
     vel = np.where(sampled[:, None], 0.0, 3.0 * L / G).astype(np.float32) * np.ones((1, 3), np.float32)
     mass = np.full(N, 1e-30, np.float32)                 # no forces to speak of: a particle at rest stays where it is
     rep = run_pair(G, pos, vel, mass, [1.0, 1.0])
@@ -147,3 +147,27 @@ def test_slabs_with_arrivals_and_leavers():
             assert np.array_equal(ia, ib) and np.array_equal(xa, xb) and np.array_equal(va, vb)
             moved += int((owner[ia] != r).sum())
         assert moved > 0                                # particles did change slabs
+
+
+def test_small_sets_when_the_environment_allows(monkeypatch):
+    """PM_REBIN_MIN (read when a context is made) lowers the size from which a binning may start from the order before:
+    a few thousand particles, whose estimate comes from the first 256 slots alone, against the sort of everything."""
+    monkeypatch.setenv("PM_REBIN_MIN", "256")
+    rng = np.random.default_rng(4)
+    n = 6000
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    vel = rng.normal(0, 1.0, (n, 3)).astype(np.float32)
+    mass = np.full(n, 1e-3, np.float32)
+    took = 0
+    with pm.Simulation(32, L, pos, vel, mass, fused_gradient=True) as a, \
+            pm.Simulation(32, L, pos, vel, mass, fused_gradient=True, full_sort=True) as b:
+        for _ in range(12):
+            a.step(0.05, 1), b.step(0.05, 1)
+            a.synchronize(), b.synchronize()
+            a.deposit(), b.deposit()
+            ka, pa = a.cell_keys()
+            kb, pb = b.cell_keys()
+            assert np.array_equal(ka, kb) and np.array_equal(pa, pb)
+            took += a.last_binning()[0]
+        assert np.array_equal(a.positions(), b.positions()) and np.array_equal(a.velocities(), b.velocities())
+    assert took > 0
