@@ -84,7 +84,7 @@ int alloc_particles(pm_ctx *c)
 // The binning starts from the order before when the drift's estimate of the movers is at most PM_REBIN_SHARE_OF /
 // PM_REBIN_SHARE of the particles.
 #ifndef PM_REBIN_SHARE
-#define PM_REBIN_SHARE 16
+#define PM_REBIN_SHARE 6
 #endif
 #ifndef PM_REBIN_SHARE_OF
 #define PM_REBIN_SHARE_OF 1

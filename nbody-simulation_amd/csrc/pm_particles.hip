@@ -1192,7 +1192,7 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
         // the bits are for a binning that starts from this order: not written while the estimates say that far too many
         // particles move for that (a set that calms down is marked from the step after the estimate says so)
         const uint32_t seen = c->movers_seen ? *c->movers_seen : 0u;
-        probe.mask = (seen == 0xffffffffu || (int64_t)seen * 4 <= n) ? c->rb_mask : nullptr;
+        probe.mask = (seen == 0xffffffffu || (int64_t)seen * 3 <= n) ? c->rb_mask : nullptr;
         c->movers_marked = probe.mask != nullptr;
     }
     auto launch = [&](auto mapped) {

@@ -42,15 +42,15 @@ __device__ __forceinline__ uint32_t lower_bound(P a, uint32_t lo, uint32_t hi, u
 // The drift has left a bit per slot of the old order's n_old slots: which hold a mover.  A thread takes four words of 64
 // slots, marks the slots from n_old on (a slab's arrivals, which have no place in the old order) and writes them back:
 // mask[g] = which of slots 64 g .. 64 g + 63 hold a mover.  A tile is RS_TILE such words: before[g] = movers in the
-// slots before 64 g, through a look-back chain over the tiles, and (mk, mi) = the movers' new keys and slots, compacted
-// in slot order.  ctl (cleared by the caller): PM_RB_TICKET hands out the tiles; the last tile writes the number of
+// slots before 64 g, through a look-back chain over the tiles; and, if mk is given, (mk, mi) = the movers' new keys and
+// slots, compacted in slot order (else k_compact_movers does that).  ctl (cleared by the caller): PM_RB_TICKET hands out the tiles; the last tile writes the number of
 // movers.  states: one look-back word per tile, cleared by the caller.
 constexpr int RS_ITEMS = 4, RS_TILE = RB_BLOCK * RS_ITEMS;
 
 __global__ void __launch_bounds__(RB_BLOCK)
-k_scan_movers(uint64_t *__restrict__ mask, const uint32_t *__restrict__ key_new, uint32_t n_old, uint32_t n,
-              uint32_t *__restrict__ before, uint32_t *__restrict__ mk, uint32_t *__restrict__ mi,
-              uint32_t *__restrict__ states, uint32_t *__restrict__ ctl)
+k_scan_movers(uint64_t *__restrict__ mask, uint32_t n_old, uint32_t n, uint32_t *__restrict__ before,
+              uint32_t *__restrict__ states, uint32_t *__restrict__ ctl,
+              const uint32_t *__restrict__ key_new, uint32_t *__restrict__ mk, uint32_t *__restrict__ mi)
 {
     __shared__ uint32_t wsum[RB_WAVES], misc[2];
     const int t = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -128,12 +128,30 @@ k_scan_movers(uint64_t *__restrict__ mask, const uint32_t *__restrict__ key_new,
         const uint32_t g = g0 + (uint32_t)i;
         if (g >= groups) break;
         before[g] = at;
-        for (uint64_t b = bits[i]; b != 0ull; b &= b - 1ull, ++at) {       // (mostly no turn at all)
+        if (mk == nullptr) { at += cnt[i]; continue; }
+        // few movers: their keys and slots are compacted here, a turn per set bit (mostly no turn at all)
+        for (uint64_t b = bits[i]; b != 0ull; b &= b - 1ull, ++at) {
             const uint32_t slot = (g << 6) + (uint32_t)(__ffsll((long long)b) - 1);
             mk[at] = key_new[slot];
             mi[at] = slot;
         }
     }
+}
+
+// The movers' new keys and slots, compacted in slot order: a thread per slot.  (The loop over the set bits of a word in
+// the kernel above does the same 20 us sooner when one particle in a hundred moves, and 60 us later when six do: the
+// caller chooses by the estimate it has.)
+__global__ void __launch_bounds__(256)
+k_compact_movers(const uint64_t *__restrict__ mask, const uint32_t *__restrict__ before, const uint32_t *__restrict__ key_new, uint32_t n,
+                 uint32_t *__restrict__ mk, uint32_t *__restrict__ mi)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t word = mask[r >> 6];
+    if (!((word >> (r & 63u)) & 1ull)) return;
+    const uint32_t at = before[r >> 6] + (uint32_t)__popcll(word & ((1ull << (r & 63u)) - 1ull));
+    mk[at] = key_new[r];
+    mi[at] = r;
 }
 
 // movers stored before slot t (t <= n)
@@ -158,15 +176,12 @@ __device__ __forceinline__ uint32_t goes_in_at(uint32_t k, uint32_t slot, const 
     return slot < first ? first : lower_bound(key_cur, first, hi, k + 1u);
 }
 
-// Sorted mover j: the slot t_j before which it goes in, and its place.  tile_first[T] = the movers that go in before the
-// first slot of tile T of the slots (T = 0 .. tiles; cleared by the caller, which is right when there are no movers): where
-// t_j lies in another tile than t_(j-1), mover j writes the entries of the tiles from the one to the other.
+// Sorted mover j: the slot t_j before which it goes in (kept in `at`), and its place.
 __global__ void __launch_bounds__(256)
 k_place_movers(const uint32_t *__restrict__ mk, const uint32_t *__restrict__ mi, const uint32_t *__restrict__ ctl,
                const uint32_t *__restrict__ key_cur, const uint32_t *__restrict__ row_start, uint32_t G,
                const uint64_t *__restrict__ mask, const uint32_t *__restrict__ before,
-               uint32_t *__restrict__ src, uint32_t *__restrict__ key_sorted, uint32_t *__restrict__ at,
-               uint32_t *__restrict__ tile_first, uint32_t tiles, uint32_t rows, uint32_t n_old)
+               uint32_t *__restrict__ src, uint32_t *__restrict__ key_sorted, uint32_t *__restrict__ at, uint32_t rows, uint32_t n_old)
 {
     const uint32_t m = ctl[PM_RB_MOVERS];
     for (uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256u) {
@@ -176,12 +191,16 @@ k_place_movers(const uint32_t *__restrict__ mk, const uint32_t *__restrict__ mi,
         src[pos] = slot;
         key_sorted[pos] = k;
         at[j] = t;
-        // tiles whose first slot lies in (t_(j-1), t_j] have j movers before them; behind the last mover, all m
-        const uint32_t from = j == 0 ? 0u : goes_in_at(mk[j - 1], mi[j - 1], key_cur, row_start, G, rows, n_old) / (uint32_t)RB_TILE + 1u;
-        for (uint32_t T = from; T <= t / (uint32_t)RB_TILE && T <= tiles; ++T) tile_first[T] = (uint32_t)j;
-        if (j + 1 == m)
-            for (uint32_t T = t / (uint32_t)RB_TILE + 1u; T <= tiles; ++T) tile_first[T] = m;
     }
+}
+
+// tile_first[T] = the movers that go in before the first slot of tile T of the slots, T = 0 .. tiles (`at` is sorted: the
+// movers are)
+__global__ void __launch_bounds__(256)
+k_tile_first(const uint32_t *__restrict__ at, const uint32_t *__restrict__ ctl, uint32_t *__restrict__ tile_first, uint32_t tiles)
+{
+    const uint32_t T = blockIdx.x * 256u + threadIdx.x;
+    if (T <= tiles) tile_first[T] = lower_bound(at, 0u, ctl[PM_RB_MOVERS], T * (uint32_t)RB_TILE);
 }
 
 // The stayers of a tile of slots: r - A(r) + B(r).  The movers that go in inside the tile (tile_first says which) are
@@ -246,15 +265,19 @@ hipError_t pm_rebin_incremental(pm_ctx *c, int bits)
     hipError_t e = pm_launch_clear(c->rb_ctl, ((PM_RB_WORDS + (size_t)stiles + tiles + 1) * sizeof(uint32_t) + 15) / 16 * 16, c->stream);
     if (e != hipSuccess) return e;
     uint32_t *ctl = c->rb_ctl, *states = c->rb_ctl + PM_RB_WORDS, *tile_first = states + stiles;
-    k_scan_movers<<<stiles, RB_BLOCK, 0, c->stream>>>(c->rb_mask, c->key_in, (uint32_t)c->order_n, n, c->rb_before, c->rb_key[0],
-                                                      c->rb_slot[0], states, ctl);
+    // (the estimate is a guide to speed, as everywhere: either way compacts the same movers)
+    const bool very_few = c->movers_seen && (int64_t)*c->movers_seen * 64 <= c->n;
+    k_scan_movers<<<stiles, RB_BLOCK, 0, c->stream>>>(c->rb_mask, (uint32_t)c->order_n, n, c->rb_before, states, ctl, c->key_in,
+                                                      very_few ? c->rb_key[0] : nullptr, c->rb_slot[0]);
+    if (!very_few) k_compact_movers<<<(n + 255u) / 256u, 256, 0, c->stream>>>(c->rb_mask, c->rb_before, c->key_in, n, c->rb_key[0], c->rb_slot[0]);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // (the workspace of the sort of the whole set, which does not run in a binning that takes this path)
     e = pm_sort_pairs_counted(c->sort_tmp, c->sort_tmp_bytes, c->rb_key[0], c->rb_key[1], c->rb_slot[0], c->rb_slot[1], n, ctl + PM_RB_MOVERS, bits,
                               c->device, c->stream);
     if (e != hipSuccess) return e;
     k_place_movers<<<1024, 256, 0, c->stream>>>(c->rb_key[1], c->rb_slot[1], ctl, c->key_out, c->row_start, (uint32_t)c->g.G, c->rb_mask, c->rb_before, c->src,
-                                                c->key_alt, c->rb_at, tile_first, tiles, (uint32_t)c->g.Gs * (uint32_t)c->g.G, (uint32_t)c->order_n);
+                                                c->key_alt, c->rb_at, (uint32_t)c->g.Gs * (uint32_t)c->g.G, (uint32_t)c->order_n);
+    k_tile_first<<<(tiles + 1u + 255u) / 256u, 256, 0, c->stream>>>(c->rb_at, ctl, tile_first, tiles);
     k_place_stayers<<<tiles, RB_BLOCK, 0, c->stream>>>(c->key_in, n, c->rb_mask, c->rb_before, c->rb_at, tile_first, c->src, c->key_alt);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     uint32_t *k = c->key_out; c->key_out = c->key_alt; c->key_alt = k;
