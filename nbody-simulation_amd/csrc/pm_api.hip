@@ -110,7 +110,7 @@ int ensure_binned(pm_ctx *c)
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
     TRY(pm_bin_order(c, bits_for(c->g.M)));
     HIP_TRY(c, pm_launch_reorder(c));
-    HIP_TRY(c, pm_launch_row_start(c));
+    if (!c->last_incremental) HIP_TRY(c, pm_launch_row_start(c));       // (the other way of binning has brought them up to date itself)
     c->binned = true;
     c->order_known = true;
     c->order_n = c->n;
