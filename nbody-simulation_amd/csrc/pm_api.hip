@@ -763,7 +763,9 @@ int pm_get_cell_keys(pm_ctx *c, int64_t *keys, int64_t *perm)
 
 int pm_last_binning(pm_ctx *c, int64_t *movers)
 {
-    if (!c || !movers) return PM_EINVAL;
+    // (the results are 0 and 1: errors are reported as negated codes)
+    if (!c) return -PM_EINVAL;
+    if (!movers) { fail(c, PM_EINVAL, "movers is NULL"); return -PM_EINVAL; }
     *movers = 0;
     if (!c->last_incremental) {
         // the drift's estimate, as the host last saw it (what the choice was made by, or a newer one)
@@ -771,10 +773,11 @@ int pm_last_binning(pm_ctx *c, int64_t *movers)
         *movers = seen == 0xffffffffu ? -1 : (int64_t)seen;
         return 0;
     }
-    HIP_TRY(c, hipSetDevice(c->device));
     uint32_t ctl[PM_RB_WORDS];
-    HIP_TRY(c, hipMemcpyAsync(ctl, c->rb_ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctl, c->rb_ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { fail(c, PM_EHIP, std::string("pm_last_binning: ") + hipGetErrorString(e)); return -PM_EHIP; }
     *movers = (int64_t)ctl[PM_RB_MOVERS];
     return 1;
 }
@@ -785,6 +788,7 @@ int pm_energies(pm_ctx *c, double *ke, double *pe)
     TRY(need_particles(c));
     if (!ke || !pe) return fail(c, PM_EINVAL, "NULL buffer");
     if ((c->flags & (PM_FLAG_NGP | PM_FLAG_F64)) && !c->potential64) return fail(c, PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
+    if (!(c->flags & (PM_FLAG_NGP | PM_FLAG_F64))) TRY(need_mesh(c, PM_MESH_POTENTIAL, "potential"));
     HIP_TRY(c, hipSetDevice(c->device));
     double *res = c->diag + 2 * 1024;
     HIP_TRY(c, pm_launch_energies(c, res, res + 1));

@@ -409,6 +409,8 @@ extern "C" int pm_energies_noalloc(pm_ctx *c, double *device_ke_pe)
         return fail(PM_EINVAL, "pm_energies_noalloc takes at most PM_NOALLOC_MAX_PARTICLES (268435456) particles: use pm_energies");
     if ((c->flags & (PM_FLAG_NGP | PM_FLAG_F64)) && !c->potential64)
         return fail(PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
+    if (!(c->flags & (PM_FLAG_NGP | PM_FLAG_F64)) && !(c->mesh_valid & (1u << PM_MESH_POTENTIAL)))
+        return fail(PM_ESTATE, "no potential yet: step, or call pm_potential / pm_set_mesh(PM_MESH_POTENTIAL) first");
     hipError_t e = hipSetDevice(c->device);
     double *partials = nullptr;
     if (e == hipSuccess) e = noalloc_scratch(c->device, &partials);

@@ -1203,7 +1203,9 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
         // the bits are for a binning that starts from this order: not written while the estimates say that far too many
         // particles move for that (a set that calms down is marked from the step after the estimate says so)
         const uint32_t seen = c->movers_seen ? *c->movers_seen : 0u;
-        probe.mask = (seen == 0xffffffffu || (int64_t)seen * 3 <= n) ? c->rb_mask : nullptr;
+        // (nor on a context whose binnings never start from the order before)
+        const bool may_rebin = !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_NGP | PM_FLAG_F64));
+        probe.mask = (may_rebin && (seen == 0xffffffffu || (int64_t)seen * 3 <= n)) ? c->rb_mask : nullptr;
         c->movers_marked = probe.mask != nullptr;
     }
     auto launch = [&](auto mapped) {

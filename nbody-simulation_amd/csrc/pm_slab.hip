@@ -255,6 +255,7 @@ int pm_slab_fft2(pm_ctx *c, int dir)
         if (dir < 0) { in[0] = c->density; out[0] = c->spectrum; FFT_TRY(c, rocfft_execute(c->slab_fwd2, in, out, c->info)); }
         else { in[0] = c->spectrum; out[0] = pot; FFT_TRY(c, rocfft_execute(c->slab_inv2, in, out, c->info)); }
     }
+    TRY(done(c));
     return PM_OK;
 }
 
@@ -276,6 +277,7 @@ int pm_slab_unpack(pm_ctx *c, const void *device_blocks)
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs, 0, c->g.Gs));
     else HIP_TRY(c, pm_launch_transpose_pack(c, (const float2 *)device_blocks, c->spectrum, true));
+    TRY(done(c));
     return PM_OK;
 }
 
@@ -313,6 +315,7 @@ int pm_slab_inverse_planes(pm_ctx *c, const void *device_blocks, int first, int 
     const size_t plane = (size_t)c->g.G * c->g.G, splane = (size_t)c->g.G * c->g.Ghp;
     HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs, first, count));
     HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, c->potential + (1 + first) * plane, c->spectrum + first * splane, count));
+    TRY(done(c));
     return PM_OK;
 }
 

@@ -76,7 +76,7 @@ class HipSlabEngine:
         movers = ctypes.c_int64(0)
         rc = self.lib.pm_last_binning(self.ctx, ctypes.byref(movers))
         if rc < 0:
-            self._check(rc)
+            self._check(-rc)
         return bool(rc), int(movers.value)
 
     def _check(self, rc):
@@ -306,7 +306,8 @@ class _Comm:
         return from_prev, from_next
 
     def exchange_counts(self, counts):
-        """counts[p] = what goes to rank p (int64 tensor, on the device for RCCL) -> what every rank p sends here."""
+        """counts: int64 tensor of world equal shares (on the device for RCCL), share p for rank p -> the shares every rank
+        sent here, in rank order."""
         if self.world == 1 and not (self.always and self.on):
             return counts.clone()
         if self.stage_on_host and counts.is_cuda:
@@ -387,10 +388,15 @@ class ThreadComm:
         return from_prev, from_next
 
     def exchange_counts(self, counts):
-        return torch.cat(self.all_to_all([counts[p:p + 1] for p in range(self.world)], [1] * self.world))
+        k = counts.numel() // self.world
+        return torch.cat(self.all_to_all([counts[p * k:(p + 1) * k] for p in range(self.world)], [k] * self.world))
 
     def barrier(self):
         self._s.barrier.wait()
+
+    def abort(self):
+        """Called by a slab's thread that gives up: every thread waiting at the barrier, now or later, gets BrokenBarrierError."""
+        self._s.barrier.abort()
 
 
 class SlabSimulation:
@@ -456,8 +462,15 @@ class SlabSimulation:
         self.close()
 
     def step(self, dt, nsteps=1):
-        for _ in range(nsteps):
-            self._step(dt)
+        try:
+            for _ in range(nsteps):
+                self._step(dt)
+        except BaseException:
+            # slabs that are threads of one process: the others must not wait at a barrier this one will never reach
+            abort = getattr(self.comm, "abort", None)
+            if abort is not None:
+                abort()
+            raise
 
     def _step(self, dt):
         e, G, Gs, world, comm = self.engine, self.G, self.Gs, self.comm.world, self.comm
@@ -526,9 +539,13 @@ class SlabSimulation:
         e.gather_kick_drift(dt)
         mark("gather_kick_drift")
         mine = e.outbox_counts()                    # world + 1 entries, where the engine's data lives
-        theirs = comm.exchange_counts(mine[:world])
+        # every rank learns of every rank's trouble word (it travels beside the count), so that all of them raise in the
+        # same step instead of one raising and the others waiting for it in the next exchange
+        pairs = torch.stack([mine[:world], mine[world:world + 1].expand(world)], dim=1).reshape(-1)
+        theirs = comm.exchange_counts(pairs)
         both = torch.cat([mine, theirs]).cpu().tolist()
-        counts, trouble, incoming = both[:world], both[world], both[world + 1:]
+        counts, incoming = both[:world], both[world + 1::2]
+        trouble = max([both[world]] + both[world + 2::2])
         if trouble:
             raise _lib.PMError("particle migration: " + ("a particle was delivered to a slab that does not own its cell"
                                                           if trouble >> 32 else f"{trouble} leavers did not fit the outbox"))

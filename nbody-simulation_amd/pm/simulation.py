@@ -269,7 +269,7 @@ class Simulation:
         movers = ctypes.c_int64(0)
         rc = self.lib.pm_last_binning(self.ctx, ctypes.byref(movers))
         if rc < 0:
-            self._ck(rc)
+            self._ck(-rc)
         return bool(rc), int(movers.value)
 
     def stage_times(self):

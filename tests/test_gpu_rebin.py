@@ -171,3 +171,15 @@ def test_small_sets_when_the_environment_allows(monkeypatch):
             took += a.last_binning()[0]
         assert np.array_equal(a.positions(), b.positions()) and np.array_equal(a.velocities(), b.velocities())
     assert took > 0
+
+
+def test_last_binning_reports_errors_as_negative_values():
+    """0 and 1 are results of pm_last_binning: its errors are negated codes, which Simulation.last_binning raises on"""
+    import ctypes
+    lib = pm.load()
+    movers = ctypes.c_int64(7)
+    assert lib.pm_last_binning(None, ctypes.byref(movers)) == -1        # -PM_EINVAL
+    with pm.Simulation(8, 100.0, np.zeros((2, 3), np.float32)) as sim:
+        assert lib.pm_last_binning(sim.ctx, None) == -1
+        assert b"NULL" in lib.pm_last_error(sim.ctx)
+        assert sim.last_binning() == (False, -1)                        # nothing binned yet, no estimate yet

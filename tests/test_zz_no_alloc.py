@@ -76,6 +76,15 @@ def test_noalloc_energies_arguments_are_checked(pm):
         sim.set_particles(np.zeros((2, 3), np.float32))
         with pytest.raises(pm.PMError, match="NULL"):
             sim.energies_noalloc(0)
+        # no solve has run and no potential was uploaded: both energy calls refuse instead of summing whatever the mesh holds
+        with pytest.raises(pm.PMError, match="no potential"):
+            sim.energies_noalloc(out.data_ptr())
+        with pytest.raises(pm.PMError, match="no potential"):
+            sim.energies()
+        sim.set_mesh(1, np.ones((8, 8, 8), np.float32))
+        sim.energies_noalloc(out.data_ptr())
+        sim.synchronize()
+        assert out.cpu().tolist() == [0.0, 1.0]                             # two unit masses at rest on a potential of ones
 
 
 def test_noalloc_energies_refuse_more_particles_than_the_scratch_is_sized_for(pm):
