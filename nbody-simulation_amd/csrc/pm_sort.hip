@@ -1,9 +1,16 @@
-// Stable LSD radix sort of (cell key, storage index) pairs for gfx950, hand-written: one kernel counts the digits of
-// every place, one turns the counts into offsets, and every place takes ONE pass over the pairs ("one sweep": a
-// workgroup learns where its share of each digit goes from the workgroups before it through a chain of look-back
-// states instead of from a separate scan over per-workgroup histograms).  Stability is what makes the cell order well
-// defined: ties keep the current storage order (functions.py:27-39 defines the cells, the order of equal cells is the
-// order the particles are stored in).
+// Stable LSD radix sort of (cell key, storage index) pairs for gfx950, hand-written.  Stability is what makes the cell
+// order well defined: ties keep the current storage order (functions.py:27-39 defines the cells, the order of equal
+// cells is the order the particles are stored in).
+//
+// A place (digit) of the keys takes one pass that ranks the pairs of a tile of 8192 by their digit and writes them to
+// their places.  Where a tile's share of each digit goes follows from the digit counts of the tiles before it, and there
+// are two ways to learn them:
+//  - a sort whose number of pairs the host knows: a counting kernel writes every tile's digit counts, a scan turns them
+//    into each tile's first place per digit, and the pass reads its row of that table.  No tile waits for another;
+//  - a sort whose number of pairs is known on the device only (the movers of pm_rebin.hip): one kernel counts the digits
+//    of every place, one turns the counts into offsets, and a tile learns its places from the tiles before it through a
+//    chain of look-back states inside the pass ("one sweep").  Fewer launches, which is what a sort of few pairs is
+//    made of; on 16.7 M pairs a pass spends 36 of its 92 us in that chain, which is why the other way exists.
 //
 // (Measured and not kept: a last pass that also fetches the position record of every pair and writes it, with its
 // fraction record, at the pair's place in cell order.  It saves reading the sorted indices again but holds a tile's
@@ -12,6 +19,7 @@
 #include "pm_internal.hpp"
 
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -132,6 +140,114 @@ k_digit_offsets(uint32_t *__restrict__ counts)
     if (threadIdx.x < SIZE) row[threadIdx.x] = before;
 }
 
+// ---- digit counts of every tile for ONE place, and their scan ------------------------------------------------------
+// tile_counts[tile][digit]: pairs of the tile (SORT_TILE consecutive pairs of the pass's input) with that digit.  A
+// thread takes SORT_ITEMS consecutive keys and adds one count per run of equal digits.
+template <typename K, unsigned RADIX>
+__global__ void __launch_bounds__(SORT_BLOCK)
+k_tile_counts(const K *__restrict__ keys, uint32_t n, uint32_t *__restrict__ tile_counts, unsigned bit, uint32_t mask)
+{
+    constexpr uint32_t SIZE = 1u << RADIX;
+    static_assert(SORT_ITEMS % 4 == 0, "keys are loaded four at a time");
+    __shared__ uint32_t table[SIZE];
+    for (uint32_t q = threadIdx.x; q < SIZE; q += SORT_BLOCK) table[q] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)SORT_TILE + threadIdx.x * (uint32_t)SORT_ITEMS;
+    if (base < n) {
+        const uint32_t have = n - base < (uint32_t)SORT_ITEMS ? n - base : (uint32_t)SORT_ITEMS;
+        K k[SORT_ITEMS];
+        if (have == (uint32_t)SORT_ITEMS) {
+            if constexpr (sizeof(K) == 4) {
+                const uint4 *src = (const uint4 *)(keys + base);
+#pragma unroll
+                for (int q = 0; q < SORT_ITEMS / 4; ++q) {
+                    const uint4 v = src[q];
+                    k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SORT_ITEMS; ++q) k[q] = keys[base + q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SORT_ITEMS; ++q) k[q] = (uint32_t)q < have ? keys[base + q] : (K)0;
+        }
+        uint32_t cur = digit_of(k[0], bit, mask), run = 1;
+#pragma unroll
+        for (int q = 1; q < SORT_ITEMS; ++q) {
+            const uint32_t d = digit_of(k[q], bit, mask);
+            if ((uint32_t)q < have) {
+                if (d == cur) ++run;
+                else { atomicAdd(table + cur, run); cur = d; run = 1; }
+            }
+        }
+        atomicAdd(table + cur, run);
+    }
+    __syncthreads();
+    uint32_t *out = tile_counts + (size_t)blockIdx.x * SIZE;
+    for (uint32_t q = threadIdx.x; q < SIZE; q += SORT_BLOCK) out[q] = table[q];
+}
+
+// The scan of that table over the tiles, in place: tile_counts[tile][digit] -> pairs with that digit in the tiles
+// before `tile`; digit_total[digit] = pairs with that digit in all tiles.  Two kernels, every access a whole row of the
+// table: the tiles are cut into at most SCAN_CHUNKS chunks of consecutive tiles; k_chunk_sums adds up the rows of each
+// chunk; k_scan_chunks gives a workgroup a chunk, has it add the sums of the chunks before its own (a thread per digit)
+// and walk its tiles with the running count.
+constexpr uint32_t SCAN_CHUNKS = 128;
+template <unsigned RADIX>
+__global__ void __launch_bounds__(1u << RADIX)
+k_chunk_sums(const uint32_t *__restrict__ tile_counts, uint32_t tiles, uint32_t per_chunk, uint32_t *__restrict__ chunk_sums)
+{
+    constexpr uint32_t SIZE = 1u << RADIX;
+    const uint32_t d = threadIdx.x, t0 = blockIdx.x * per_chunk, t1 = t0 + per_chunk < tiles ? t0 + per_chunk : tiles;
+    uint32_t sum = 0;
+    uint32_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = tile_counts[(size_t)(t + q) * SIZE + d];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += v[q];
+    }
+    for (; t < t1; ++t) sum += tile_counts[(size_t)t * SIZE + d];
+    chunk_sums[(size_t)blockIdx.x * SIZE + d] = sum;
+}
+
+template <unsigned RADIX>
+__global__ void __launch_bounds__(1u << RADIX)
+k_scan_chunks(uint32_t *__restrict__ tile_counts, uint32_t tiles, uint32_t per_chunk, const uint32_t *__restrict__ chunk_sums,
+              uint32_t *__restrict__ digit_total)
+{
+    constexpr uint32_t SIZE = 1u << RADIX;
+    const uint32_t d = threadIdx.x, t0 = blockIdx.x * per_chunk, t1 = t0 + per_chunk < tiles ? t0 + per_chunk : tiles;
+    // the first workgroup also adds up all chunks: the digit's total
+    const uint32_t upto = blockIdx.x == 0 ? gridDim.x : blockIdx.x;
+    uint32_t before = 0;
+    uint32_t c = 0;
+    for (; c + 8 <= upto; c += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = chunk_sums[(size_t)(c + q) * SIZE + d];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) before += v[q];
+    }
+    for (; c < upto; ++c) before += chunk_sums[(size_t)c * SIZE + d];
+    if (blockIdx.x == 0) { digit_total[d] = before; before = 0; }
+    uint32_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = tile_counts[(size_t)(t + q) * SIZE + d];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { tile_counts[(size_t)(t + q) * SIZE + d] = before; before += v[q]; }
+    }
+    for (; t < t1; ++t) {
+        const uint32_t v = tile_counts[(size_t)t * SIZE + d];
+        tile_counts[(size_t)t * SIZE + d] = before;
+        before += v;
+    }
+}
+
 // ---- where a pass puts a pair --------------------------------------------------------------------------------------
 
 // the sorted pairs, nothing else.  NARROW: fewer than 2^30 pairs of 4-byte keys, so a pair's place times four fits 32
@@ -195,11 +311,15 @@ constexpr uint32_t LOOK = PM_SORT_LOOK;             // states of earlier tiles r
 // ON_DEVICE: the number of pairs is *n_dev, known on the device only.  The grid then has a fixed, modest number of
 // workgroups, each of which takes tiles until none is left -- so that a sort of few pairs (or of none) does not pay for
 // the start of as many workgroups as the most pairs there could be would need.
-template <typename K, typename S, unsigned RADIX, bool COUNTED, bool ON_DEVICE, class Sink>
+// CHAINED = false: tile b is workgroup b's, `digit_base` holds the pairs with each digit in all tiles (k_scan_tiles'
+// digit_total) and `states` is the scanned table of tile counts, of which the workgroup reads row b: no ticket, no
+// look-back, nothing is published.
+template <typename K, typename S, unsigned RADIX, bool COUNTED, bool ON_DEVICE, bool CHAINED, class Sink>
 __global__ void __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(PM_PASS_WAVES)))
 k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n, const uint32_t *__restrict__ digit_base,
              S *__restrict__ states, uint32_t *__restrict__ ticket, unsigned bit, uint32_t mask, Sink sink, const uint32_t *__restrict__ n_dev)
 {
+    static_assert(CHAINED || !ON_DEVICE, "a sort whose size the host does not know goes through the look-back chain");
     if constexpr (ON_DEVICE) {
         n = *n_dev;
         if ((uint64_t)blockIdx.x * SORT_TILE >= n) return;      // more workgroups than tiles: these take no ticket
@@ -220,10 +340,18 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
   // its second tile only after its first is done, which waits for the second tile of the workgroup before it: the
   // pass becomes one chain, 8 ms instead of 90 us.)
   for (;;) {                                            // (one turn unless ON_DEVICE)
-    if (t == 0) misc[0] = atomicAdd(ticket, 1u);
+    if constexpr (CHAINED) { if (t == 0) misc[0] = atomicAdd(ticket, 1u); }
     for (uint32_t q = t; q < SORT_WAVES * SIZE; q += SORT_BLOCK) whist[q] = 0u;
+    // (not chained: what the scan left for this tile and the digit totals are on their way while the pairs are ranked)
+    uint32_t earlier_tiles = 0, digit_all = 0;
+    if constexpr (!CHAINED) {
+        if ((uint32_t)t < SIZE) {
+            earlier_tiles = ((const uint32_t *)states)[(size_t)blockIdx.x * SIZE + t];
+            digit_all = digit_base[t];
+        }
+    }
     __syncthreads();
-    const uint32_t tile = misc[0];
+    const uint32_t tile = CHAINED ? misc[0] : blockIdx.x;
     const uint32_t base = tile * (uint32_t)SORT_TILE;
     if (base >= n) return;                              // (ON_DEVICE: no tile is left; else never: the grid has exactly the tiles there are)
     const uint32_t count = n - base < (uint32_t)SORT_TILE ? n - base : (uint32_t)SORT_TILE;
@@ -280,10 +408,20 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
             run += c;
         }
         total = run;
-        __hip_atomic_store(states + (size_t)tile * SIZE + t, (S)((tile == 0 ? state_bits<S>::PREFIX : state_bits<S>::PARTIAL) | (S)total),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (CHAINED)
+            __hip_atomic_store(states + (size_t)tile * SIZE + t, (S)((tile == 0 ? state_bits<S>::PREFIX : state_bits<S>::PARTIAL) | (S)total),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint32_t before = block_exclusive_sum(total, misc + 1);
+    if constexpr (!CHAINED) {
+        // first place of a digit in the output: the pairs with smaller digits in all tiles, then those with this digit in
+        // the tiles before this one
+        const uint32_t smaller = block_exclusive_sum(digit_all, misc + 1);
+        if ((uint32_t)t < SIZE) {
+            dstart[t] = before;
+            gdelta[t] = smaller + earlier_tiles - before;
+        }
+    } else
     if ((uint32_t)t < SIZE) {
         uint32_t earlier = 0;                           // pairs with this digit in the tiles before this one
 #ifdef PM_SORT_NOCHAIN
@@ -396,7 +534,9 @@ sort_plan plan_sort(size_t n, unsigned bits, unsigned radix_bits, size_t key_byt
     p.tickets = 0;
     p.counts = aligned(p.places * sizeof(uint32_t));
     p.states = p.counts + aligned((size_t)p.places * p.size * sizeof(uint32_t));
-    p.cleared = p.states + aligned((size_t)p.places * p.size * p.tiles * (p.wide ? 8 : 4));
+    // (look-back states of every place; or, for the other way, one table of tile counts and the sums of its chunks)
+    const size_t chain_states = (size_t)p.places * p.size * p.tiles * (p.wide ? 8 : 4), table = ((size_t)p.tiles + SCAN_CHUNKS) * p.size * 4;
+    p.cleared = p.states + aligned(chain_states > table ? chain_states : table);
     p.keys_tmp = p.cleared;
     p.values_tmp = p.keys_tmp + aligned(n * key_bytes);
     p.bytes = p.values_tmp + aligned(n * sizeof(uint32_t));
@@ -416,15 +556,15 @@ unsigned place_bits(unsigned bits)
 #endif
 template <typename K, typename S, unsigned RADIX, bool COUNTED, class Sink>
 hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, size_t n, const uint32_t *digit_base, void *states, uint32_t *ticket, unsigned bit,
-                       unsigned now, Sink sink, int device, hipStream_t s, pm_ctx *timed, const uint32_t *n_dev)
+                       unsigned now, Sink sink, int device, hipStream_t s, pm_ctx *timed, const uint32_t *n_dev, bool chained)
 {
     constexpr size_t lds = pass_lds_bytes<K, RADIX>();
     auto allow = [&](const void *kernel) -> hipError_t {
         if (lds <= 64 * 1024) return hipSuccess;
         // more LDS than a kernel gets by default: allowed once per kernel and device (a bit per device; setting it
         // twice from two threads is harmless)
-        static std::atomic<uint64_t> allowed[2] = {};
-        std::atomic<uint64_t> &a = allowed[n_dev ? 1 : 0];
+        static std::atomic<uint64_t> allowed[3] = {};
+        std::atomic<uint64_t> &a = allowed[n_dev ? 1 : chained ? 0 : 2];
         const uint64_t bit_of = 1ull << (device & 63);
         if (a.load(std::memory_order_acquire) & bit_of) return hipSuccess;
         hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -433,18 +573,36 @@ hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, si
     };
     pm_timer timer(timed, PM_NSTAGES + PM_KERNEL_SORT_PASS);
     if (n_dev) {
-        auto kernel = k_radix_pass<K, S, RADIX, COUNTED, true, Sink>;
+        auto kernel = k_radix_pass<K, S, RADIX, COUNTED, true, true, Sink>;
         hipError_t e = allow((const void *)kernel);
         if (e != hipSuccess) return e;
         const unsigned grid = p.tiles < (unsigned)PM_SORT_DEVICE_GRID ? p.tiles : (unsigned)PM_SORT_DEVICE_GRID;
         kernel<<<grid, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink, n_dev);
+    } else if (chained) {
+        auto kernel = k_radix_pass<K, S, RADIX, COUNTED, false, true, Sink>;
+        hipError_t e = allow((const void *)kernel);
+        if (e != hipSuccess) return e;
+        kernel<<<p.tiles, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink, n_dev);
     } else {
-        auto kernel = k_radix_pass<K, S, RADIX, COUNTED, false, Sink>;
+        auto kernel = k_radix_pass<K, S, RADIX, COUNTED, false, false, Sink>;
         hipError_t e = allow((const void *)kernel);
         if (e != hipSuccess) return e;
         kernel<<<p.tiles, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink, n_dev);
     }
     return hipGetLastError();
+}
+
+// Sorts of fewer tiles than this keep the look-back chain (fewer launches).  The environment variable
+// PM_SORT_CHAIN_TILES, read once, sets another bound (tests: 0 sends every sort the other way, a huge value none).
+unsigned chain_below_tiles()
+{
+    static const unsigned bound = [] {
+        const char *v = std::getenv("PM_SORT_CHAIN_TILES");
+        char *end = nullptr;
+        const unsigned long long m = v ? std::strtoull(v, &end, 10) : 0ull;
+        return (v && end != v) ? (unsigned)(m > 0xffffffffull ? 0xffffffffull : m) : 64u;
+    }();
+    return bound;
 }
 
 // Sorts n (key, value) pairs by the low `bits` bits of the keys, values going in as 0, 1, 2, ... (vin == nullptr) or
@@ -461,14 +619,19 @@ hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const 
     S *states = (S *)(w + p.states);
     K *ktmp = (K *)(w + p.keys_tmp);
     uint32_t *vtmp = (uint32_t *)(w + p.values_tmp);
-    hipError_t e = pm_launch_clear(w, p.cleared, s);
-    if (e != hipSuccess) return e;
-    const size_t per_count = (size_t)PM_COUNT_BLOCK * COUNT_ITEMS;
-    const size_t want = (n + per_count - 1) / per_count;
-    k_digit_counts<K, RADIX><<<(unsigned)(want < PM_COUNT_GRID ? want : PM_COUNT_GRID), PM_COUNT_BLOCK, (size_t)p.places * p.size * sizeof(uint32_t), s>>>(
-        kin, counts, (uint32_t)n, bits, n_dev);
-    k_digit_offsets<RADIX><<<p.places, SORT_BLOCK, 0, s>>>(counts);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // Which way the tiles learn their places (see the top of the file).  The table of tile counts is written whole by the
+    // counting kernel of each pass: nothing to clear.  A sort of a few tiles is all launches: it keeps the chain.
+    const bool chained = n_dev != nullptr || p.tiles < chain_below_tiles() || sizeof(S) != 4;
+    hipError_t e = hipSuccess;
+    if (chained) {
+        if ((e = pm_launch_clear(w, p.cleared, s)) != hipSuccess) return e;
+        const size_t per_count = (size_t)PM_COUNT_BLOCK * COUNT_ITEMS;
+        const size_t want = (n + per_count - 1) / per_count;
+        k_digit_counts<K, RADIX><<<(unsigned)(want < PM_COUNT_GRID ? want : PM_COUNT_GRID), PM_COUNT_BLOCK, (size_t)p.places * p.size * sizeof(uint32_t), s>>>(
+            kin, counts, (uint32_t)n, bits, n_dev);
+        k_digit_offsets<RADIX><<<p.places, SORT_BLOCK, 0, s>>>(counts);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     // the passes alternate between the scratch and the output so that the last one ends in the output
     bool to_output = (p.places - 1) % 2 == 0, from_input = true;
     for (unsigned place = 0, bit = 0; place < p.places; ++place, bit += RADIX) {
@@ -480,13 +643,25 @@ hipError_t sort_pairs(void *tmp, size_t tmp_bytes, const K *kin, K *kout, const 
         const uint32_t *base = counts + (size_t)place * p.size;
         S *st = states + (size_t)place * p.size * p.tiles;
         const bool counted = from_input && vin == nullptr;
+        if (!chained) {
+            // (the first place's part of the areas the chain would use: digit totals, the table of tile counts)
+            base = counts; st = states;
+            k_tile_counts<K, RADIX><<<p.tiles, SORT_BLOCK, 0, s>>>(ki, (uint32_t)n, (uint32_t *)st, bit, (1u << now) - 1u);
+            // (the chunk sums live behind the table of tile counts, in the part of the area the chain's later places would use)
+            const uint32_t per_chunk = (p.tiles + SCAN_CHUNKS - 1) / SCAN_CHUNKS < 8 ? 8 : (p.tiles + SCAN_CHUNKS - 1) / SCAN_CHUNKS;
+            const uint32_t chunks = (p.tiles + per_chunk - 1) / per_chunk;
+            uint32_t *chunk_sums = (uint32_t *)st + (size_t)p.tiles * p.size;
+            k_chunk_sums<RADIX><<<chunks, p.size, 0, s>>>((const uint32_t *)st, p.tiles, per_chunk, chunk_sums);
+            k_scan_chunks<RADIX><<<chunks, p.size, 0, s>>>((uint32_t *)st, p.tiles, per_chunk, chunk_sums, counts);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
         if (place + 1 == p.places) {
-            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed, n_dev)
-                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed, n_dev);
+            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed, n_dev, chained)
+                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, last, device, s, timed, n_dev, chained);
         } else {
             const pair_sink<K> mid{ko, vo};
-            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed, n_dev)
-                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed, n_dev);
+            e = counted ? launch_pass<K, S, RADIX, true>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed, n_dev, chained)
+                        : launch_pass<K, S, RADIX, false>(p, ki, vi, n, base, st, tickets + place, bit, now, mid, device, s, timed, n_dev, chained);
         }
         if (e != hipSuccess) return e;
         from_input = false;
