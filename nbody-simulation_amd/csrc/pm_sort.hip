@@ -593,16 +593,14 @@ hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, si
 }
 
 // Sorts of fewer tiles than this keep the look-back chain (fewer launches).  The environment variable
-// PM_SORT_CHAIN_TILES, read once, sets another bound (tests: 0 sends every sort the other way, a huge value none).
+// PM_SORT_CHAIN_TILES sets another bound (tests: 0 sends every sort the other way, a huge value none).
 unsigned chain_below_tiles()
 {
-    static const unsigned bound = [] {
-        const char *v = std::getenv("PM_SORT_CHAIN_TILES");
-        char *end = nullptr;
-        const unsigned long long m = v ? std::strtoull(v, &end, 10) : 0ull;
-        return (v && end != v) ? (unsigned)(m > 0xffffffffull ? 0xffffffffull : m) : 64u;
-    }();
-    return bound;
+    const char *v = std::getenv("PM_SORT_CHAIN_TILES");
+    if (!v) return 64u;
+    char *end = nullptr;
+    const unsigned long long m = std::strtoull(v, &end, 10);
+    return end != v ? (unsigned)(m > 0xffffffffull ? 0xffffffffull : m) : 64u;
 }
 
 // Sorts n (key, value) pairs by the low `bits` bits of the keys, values going in as 0, 1, 2, ... (vin == nullptr) or

@@ -76,8 +76,19 @@ def test_wrap_returns_box_size_like_numpy(pm, golden):
         assert np.array_equal(sim.positions().ravel(), g["wrap_out"][:n])
 
 
+@pytest.fixture(params=["as shipped", "order from the order before, sort without look-back"])
+def binning_ways(request, monkeypatch):
+    """The golden vectors are small sets, which are binned by the look-back sort of everything.  The second way sends
+    them through the code the large sets take: PM_REBIN_MIN (read by pm_create) lets a set of 256 particles put its cell
+    order together from the order before, PM_SORT_CHAIN_TILES = 0 sends every sort through the counting kernel and scan."""
+    if request.param != "as shipped":
+        monkeypatch.setenv("PM_REBIN_MIN", "256")
+        monkeypatch.setenv("PM_SORT_CHAIN_TILES", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["uniform_n10000_g32.npz", "c1mini_g50.npz"])
-def test_step0_stages(pm, golden, name):
+def test_step0_stages(pm, golden, name, binning_ways):
     from pm import functions as F
     g = golden(name)
     G, L = int(g["G"]), int(g["L"])
@@ -108,7 +119,7 @@ def test_step0_stages(pm, golden, name):
 
 @pytest.mark.parametrize("name", ["uniform_n10000_g32.npz", "c1mini_g50.npz"])
 @pytest.mark.parametrize("fused", [False, True])
-def test_k_steps(pm, golden, name, fused):
+def test_k_steps(pm, golden, name, fused, binning_ways):
     g = golden(name)
     G, L, dt, K = int(g["G"]), int(g["L"]), float(g["dt"]), int(g["K"])
     with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"], fused_gradient=fused) as sim:
@@ -155,13 +166,13 @@ def test_fused_step_512(pm):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])     # the same bits, in fact
 
 
-def test_cell_order_over_steps(pm, golden):
+def test_cell_order_over_steps(pm, golden, binning_ways):
     """Cell order = stable sort by key of the storage order, which is the previous cell order."""
     g = golden("uniform_n10000_g32.npz")
     G, L, dt = int(g["G"]), int(g["L"]), float(g["dt"])
     with pm.Simulation(G, L, g["pos0"], g["vel0"], g["mass"]) as sim:
         storage = np.arange(len(g["pos0"]))             # original index of each storage slot
-        for step in range(4):
+        for step in range(6):
             x = sim.positions()                         # original order
             keys, perm = sim.cell_keys()
             k_storage = O.cell_keys(x, G, L)[storage]
@@ -170,6 +181,7 @@ def test_cell_order_over_steps(pm, golden):
             assert np.array_equal(perm, storage), step
             assert np.array_equal(keys, k_storage[order]), step
             sim.step(dt)
+            sim.synchronize()                           # (the drift's estimate of its movers has reached the host)
 
 
 def test_results_do_not_depend_on_input_order(pm, golden):
@@ -285,6 +297,41 @@ def test_headline_size_properties(pm):
     dx = np.abs(x_staged.astype(np.float64) - xo)
     assert np.minimum(dx, L - dx).max() <= 1e-5 * L
     assert np.abs(v_staged - vo).max() <= 1e-5 * np.abs(vo).max()
+
+
+def test_headline_size_uniform_set_against_oracle(pm):
+    """The uniform particle set of the headline size (N = 16,777,216 on 512^3; 0.8 % of its particles change their cell
+    per step, so its binnings start from the order before): after every one of three steps the whole cell order -- keys
+    and permutation -- bit for bit against the oracle's keys and stable sort of the storage order, and the trajectory
+    within 1e-5 L and 1e-5 max|v| of the oracle's."""
+    import bench
+    n, G, L, dt = 16_777_216, 512, 10000, 0.005
+    pos, vel, mass = bench.make_workload("uniform", n, L, 1052)
+    xo, vo = pos, vel
+    storage = np.arange(n)
+    took = []
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+        for step in range(4):
+            keys, perm = sim.cell_keys()                # (bins the particles as they are now)
+            took.append(sim.last_binning()[0])
+            k_storage = O.cell_keys(xo, G, L)[storage]
+            order = O.sort_order(k_storage)
+            storage = storage[order]
+            assert np.array_equal(perm, storage), step
+            assert np.array_equal(keys, k_storage[order]), step
+            if step == 3:
+                break
+            sim.step(dt)
+            sim.synchronize()
+            xo_next, vo = O.pm_step(xo, vo, mass, G, L, dt)
+            x = sim.positions()
+            dx = np.abs(x.astype(np.float64) - xo_next)
+            assert np.minimum(dx, L - dx).max() <= 1e-5 * L, step
+            assert np.abs(sim.velocities() - vo).max() <= 1e-5 * np.abs(vo).max(), step
+            # the next comparison of cell orders is about the binning, not about the last bits of the solve: the oracle
+            # goes on from the engine's own positions (float32 both, so the keys are computed from the same numbers)
+            xo, vo = x, sim.velocities()
+    assert took == [False, True, True, True], took
 
 
 def test_single_fourier_mode(pm):

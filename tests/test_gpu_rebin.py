@@ -61,6 +61,35 @@ def test_few_movers_same_order(G, clumped):
         assert inc and 0 < movers < N // 8, rep
 
 
+def test_order_from_the_order_before_against_the_oracle():
+    """The binning that starts from the order before, directly against the oracle (not against another binning of this
+    library): 2^21 particles on 128^3, five steps; after each the cell order -- stable sort by O.cell_keys of the storage
+    order, which is the cell order of the step before -- keys and permutation bit for bit, and the trajectory against
+    O.pm_step within 1e-5 L and 1e-5 max|v|."""
+    from oracle import pm_oracle as O
+    G, dt = 128, 0.01
+    pos, vel, mass = make(11, 2.0)
+    xo, vo = pos, vel
+    storage = np.arange(N)
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+        for step in range(6):
+            keys, perm = sim.cell_keys()
+            inc, movers = sim.last_binning()
+            k_storage = O.cell_keys(sim.positions(), G, L)[storage]
+            order = O.sort_order(k_storage)
+            storage = storage[order]
+            assert np.array_equal(perm, storage), step
+            assert np.array_equal(keys, k_storage[order]), step
+            if step > 0:
+                assert inc is True and 0 < movers < N // 8, (step, inc, movers)
+            sim.step(dt)
+            sim.synchronize()
+            xo, vo = O.pm_step(xo, vo, mass, G, L, dt)
+        dx = np.abs(sim.positions().astype(np.float64) - xo)
+        assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+        assert np.abs(sim.velocities() - vo).max() <= 1e-5 * np.abs(vo).max()
+
+
 def test_nearly_everyone_moves():
     """The drift estimates its movers from a sample of its workgroups of 256 slots (of this set: every 8th).  Here exactly those slots hold particles
     at rest and all others move a cell or more: the estimate says `none`, the binning starts from the old order, finds
