@@ -215,6 +215,12 @@ def parse_args():
     ap.add_argument("--transpose-chunks", type=int, default=None,
                     help="slab runs: groups of planes the two all-to-all transposes are cut into and overlapped with the transforms "
                          "(default: 2 from a 1024^3 mesh on, else 1)")
+    ap.add_argument("--balance", default="auto", choices=["auto", "on", "off"],
+                    help="slab runs: hold the particles by windows of equal particle count instead of by slab (auto: when the "
+                         "fullest slab would hold more than 1.2 shares of the set)")
+    ap.add_argument("--balance-every", type=int, default=8,
+                    help="slab runs with windows: every so many steps the windows are cut anew if the fullest rank is 1.2 shares "
+                         "or more (0: the windows stay as they were cut at the start)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="--parallelism slab: torch.distributed backend (gloo stages the exchanges through the host: for "
                          "rehearsing the multi-rank run on a box with fewer GPUs than ranks)")
@@ -368,7 +374,8 @@ def main():
             "metric": metric_name(args),
             "value": world * n * args.steps / elapsed, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            # (--gpus N runs this same workload over N GPUs; replicas are N copies of it)
+            "higher_is_better": True, "scaling": "weak" if world > 1 else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (drawn on the device)" if args.device_ic else "synthetic",
             "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "fused_gradient": fused,
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
@@ -413,10 +420,13 @@ def main():
 
 
 def slab_main(args, rank, world, local_rank):
-    """ONE simulation of the workload, the mesh cut into `world` slabs: strong scaling."""
+    """ONE simulation of the workload, the mesh cut into `world` slabs: strong scaling.  --balance: the particles are
+    held by windows of equal particle count instead of by slab (auto: when the fullest slab would hold more than 1.2
+    shares of the set).  --device-ic: every rank draws its share of the set on its GPU (no host arrays)."""
     import torch
     import torch.distributed as dist
-    from pm.distributed import SlabSimulation, slab_of
+    from pm import _lib
+    from pm.distributed import SlabSimulation, balanced_cuts, equal_cuts, generated_plane_counts, owner_by_cuts, plane_of
     torch.cuda.set_device(local_rank)
     red = "cuda" if args.backend == "nccl" else "cpu"        # where the few scalars reduced below live
     if world > 1:
@@ -427,77 +437,126 @@ def slab_main(args, rank, world, local_rank):
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     n, G, L = args.n, args.grid, BOX
-    pos, vel, mass = make_workload(args.workload, n, L, 1052)
-    mine = slab_of(pos, G, L, world) == rank
-    ids = np.arange(n, dtype=np.uint32)[mine]
-    sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], ids, device_index=local_rank, capacity=int(mine.sum() * 1.3) + (1 << 20),
-                         transpose_chunks=args.transpose_chunks)
-    n_local = int(mine.sum())
-    del pos, vel, mass
+    m = G ** 3
+    Gs = G // world
 
+    def make_sim(workload):
+        """(simulation, particles per rank at the start, the windows' cuts or None)"""
+        seed = 1052
+        if args.device_ic:
+            counts = generated_plane_counts(G, L, workload, n, seed, local_rank)
+            pos = None
+        else:
+            pos, vel, mass = make_workload(workload, n, L, seed)
+            counts = np.bincount(plane_of(pos, G, L), minlength=G)
+        by_slab = counts.reshape(world, Gs).sum(axis=1)
+        balance = world > 1 and (args.balance == "on" or (args.balance == "auto" and by_slab.max() > 1.2 * n / world))
+        wmax = min(G - 3, max(Gs, G // 2))
+        cuts = balanced_cuts(counts, world, wmax, 0.5 * n / G) if balance else equal_cuts(G, world)
+        loads = [int(counts[a:b].sum()) for a, b in zip(cuts, cuts[1:])]
+        cap = int(max(loads[rank], n // world) * 1.3) + (1 << 20)
+        kw = dict(device_index=local_rank, capacity=cap, transpose_chunks=args.transpose_chunks)
+        if balance:
+            kw.update(cuts=cuts, window_planes=wmax, balance_every=args.balance_every, balance_threshold=1.2)
+        if args.device_ic:
+            sim = SlabSimulation(G, L, None, None, None, None, generate=(workload, n, seed, None), **kw)
+        else:
+            mine = owner_by_cuts(pos, G, L, cuts) == rank
+            sim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], np.arange(n, dtype=np.uint32)[mine], **kw)
+        return sim, loads, (cuts if balance else None)
+
+    def max_over_ranks(values):
+        t = torch.tensor(values, dtype=torch.float64, device=red)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    sim, loads, cuts = make_sim(args.workload)
     warm_up(sim, args.warmup)
     sim.synchronize()
     t0 = time.perf_counter()
     sim.step(DT, args.steps)
     sim.synchronize()
-    elapsed = time.perf_counter() - t0
-    # where the time goes: a few more steps with a mark after every phase (largest value over the ranks)
+    elapsed = max_over_ranks([time.perf_counter() - t0])[0]
+    # where the time goes: a few more steps with a mark after every phase, and HIP events around the kernels of this rank's
+    # context (largest value over the ranks for the phases; the kernels of the rank whose step is the longest)
     sim.profile = True
+    sim.engine.set_timing(True)
     k_prof = max(1, min(args.steps, 5))
     sim.step(DT, k_prof)
     phases = sim.phase_times()
+    kernels = sim.engine.kernel_times()
+    sim.engine.set_timing(False)
     sim.profile = False
-    pt = torch.tensor([phases[p] / k_prof for p in sim.PHASES], dtype=torch.float64, device=red)
+    local_ms = sum(phases[p] for p in ("deposit", "fft_zy", "solve_x", "ifft_yz", "gather_kick_drift")) / k_prof
+    phases = dict(zip(sim.PHASES, (round(x, 4) for x in max_over_ranks([phases[p] / k_prof for p in sim.PHASES]))))
+    kper = [kernels[k][0] / kernels[k][1] if kernels[k][1] else 0.0 for k in _lib.KERNELS]
+    n_now = sim.engine.n
+    # every rank's local work, kernel averages and particle count, gathered on all ranks (a few numbers each)
+    mine = torch.tensor([local_ms, float(n_now)] + kper, dtype=torch.float64, device=red)
+    every = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
-        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
-    phases = {p: round(float(v), 4) for p, v in zip(sim.PHASES, pt)}
-    loads = [n_local]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        l = torch.zeros(world, dtype=torch.int64, device=red)
-        l[rank] = n_local
-        dist.all_reduce(l)
-        loads = [int(x) for x in l]
+        dist.all_gather(every, mine)
+    else:
+        every = [mine]
+    every = [[float(x) for x in t] for t in every]
+    slowest = max(range(world), key=lambda r: every[r][0])
+    group_world = dist.get_world_size() if world > 1 else 1
+    group_backend = dist.get_backend() if world > 1 else None
+    final_cuts, recuts = list(sim.cuts), sim.rebalanced
     sim.close()
     # beside the headline: the uniform set of the same size over the same slabs (it divides evenly, the collision does not)
     also = None
     if args.workload == "two_galaxy" and not args.no_uniform:
-        pos, vel, mass = make_workload("uniform", n, L, 1052)
-        mine = slab_of(pos, G, L, world) == rank
-        usim = SlabSimulation(G, L, pos[mine], vel[mine], mass[mine], np.arange(n, dtype=np.uint32)[mine], device_index=local_rank,
-                              capacity=int(mine.sum() * 1.3) + (1 << 20), transpose_chunks=args.transpose_chunks)
-        del pos, vel, mass
+        usim, _, _ = make_sim("uniform")
         warm_up(usim, args.warmup)
         usim.synchronize()
         t0 = time.perf_counter()
         usim.step(DT, args.steps)
         usim.synchronize()
-        ue = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([ue], dtype=torch.float64, device=red)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ue = float(t[0])
+        ue = max_over_ranks([time.perf_counter() - t0])[0]
         usim.close()
         also = {"workload": f"uniform N={n} G={G} L={L} dt={DT}", "value": n * args.steps / ue, "unit": "particle-updates/s",
                 "ms_per_step": ue / args.steps * 1e3,
-                "step_roofline_frac": (64 * n + 80 * G ** 3) / (ue / args.steps) / 1e9 / (HBM_PEAK_GBPS * world)}
+                "step_roofline_frac": (64 * n + 80 * m) / (ue / args.steps) / 1e9 / (HBM_PEAK_GBPS * world)}
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        b_step = 64 * n + 80 * G ** 3
+        b_step = 64 * n + 80 * m
         ach = b_step / (ms_step * 1e-3) / 1e9
-        print(json.dumps({
+        # the dominant kernel of the slowest rank: the longest single launch among those with algorithmic bytes, priced with
+        # the bytes that launch cannot avoid on that rank's share (its particles; its planes of the mesh)
+        n_slow = int(every[slowest][1])
+        kb = kernel_bytes(n_slow, m // world, True)
+        kslow = dict(zip(_lib.KERNELS, every[slowest][2:]))
+        priced = [k for k in kb if kb[k][1] > 0 and kslow[k] > 0]
+        out = {
             "metric": metric_name(args), "value": n * args.steps / elapsed,
             "unit": "particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {G // world} planes",
-                       "particles_per_slab_at_start": loads, "backend": args.backend if world > 1 else None,
-                       "collective_world_size": world, "transpose_chunks": sim.transpose_chunks},
-            "phases_ms": phases, "uniform_set": also,
-            "roofline": {"bound": "hbm", "kernel": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
-                         "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None, "algorithmic_bytes_per_launch": b_step,
-                         "ms_per_launch": ms_step}}), flush=True)
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (drawn on the device)" if args.device_ic else "synthetic",
+            "config": {"workload": f"{args.workload} N={n} G={G} L={L} dt={DT}", "parallelism": f"{world} slabs of {Gs} planes",
+                       "particle_ownership": "windows of equal particle count" if cuts else "by slab",
+                       "window_cuts_at_start": cuts, "window_cuts_at_end": final_cuts if cuts else None, "recuts": recuts,
+                       "particles_per_rank_at_start": loads, "particles_per_rank_at_end": [int(e[1]) for e in every],
+                       "backend": group_backend, "collective_world_size": group_world, "transpose_chunks": sim.transpose_chunks},
+            "phases_ms": phases, "local_work_ms_per_rank": [round(e[0], 4) for e in every],
+            "kernel_ms_per_rank": [dict(zip(_lib.KERNELS, (round(x, 5) for x in e[2:]))) for e in every],
+            "uniform_set": also,
+            "step_roofline": {"bound": "hbm", "what": "whole step, all slabs", "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                              "frac": ach / (HBM_PEAK_GBPS * world), "algorithmic_bytes_per_step": b_step}}
+        if priced:
+            dom = max(priced, key=lambda k: kslow[k])
+            dach = kb[dom][1] / (kslow[dom] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": kb[dom][0].replace("<G,", f"<{G},"), "rank": slowest, "achieved": dach, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": dach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": kb[dom][1],
+                               "ms_per_launch": kslow[dom], "particles_on_that_rank": n_slow}
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": ach, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                               "frac": ach / (HBM_PEAK_GBPS * world), "traffic": None}
+        if args.cpu_baseline == "auto" and world == 1 and not args.device_ic:
+            pos, vel, mass = make_workload(args.workload, n, L, 1052)
+            out["cpu_baseline"] = cpu_baseline(pos, vel, mass, G, L, DT)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

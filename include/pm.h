@@ -36,8 +36,9 @@ enum { PM_OK = 0, PM_EINVAL = 1, PM_ENOMEM = 2, PM_EHIP = 3, PM_EFFT = 4, PM_EST
 /* host dtypes of particle arrays */
 enum { PM_F32 = 0, PM_F64 = 1 };
 
-/* meshes addressable by pm_get_mesh / pm_set_mesh; PM_SLAB_ZSPECTRUM is for pm_slab_planes only */
-enum { PM_MESH_DENSITY = 0, PM_MESH_POTENTIAL = 1, PM_MESH_GX = 2, PM_MESH_GY = 3, PM_MESH_GZ = 4, PM_SLAB_ZSPECTRUM = 5 };
+/* meshes addressable by pm_get_mesh / pm_set_mesh; the PM_SLAB_* selectors are for pm_slab_planes only */
+enum { PM_MESH_DENSITY = 0, PM_MESH_POTENTIAL = 1, PM_MESH_GX = 2, PM_MESH_GY = 3, PM_MESH_GZ = 4, PM_SLAB_ZSPECTRUM = 5,
+       PM_SLAB_MESH_ZSPECTRUM = 6, PM_SLAB_MESH_POTENTIAL = 7 };
 
 /* pm_create flags */
 enum {
@@ -247,6 +248,46 @@ int pm_forces_f64(pm_ctx *ctx);
  */
 pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags,
                        int plane0, int nplanes);
+/* Particle ownership apart from the mesh slabs, for particle sets that do not spread evenly over the planes of the mesh
+ * (two galaxies in mid-box: the fullest of eight equal slabs holds half of the particles).  The reference has one process
+ * and no counterpart; what must stay as it is are the cells of functions.py:27-39, the wrap i1 = (i + 1) % G of
+ * functions.py:56 and the positions after main.py:58-60.  A context made by pm_create_slab_windowed still transforms mesh
+ * planes [plane0, plane0 + nplanes), but the particles it holds are those whose cell has its i in a WINDOW of planes that
+ * pm_slab_set_window chooses, at most window_planes of them (nplanes <= window_planes <= grid_size - 3; needs
+ * PM_FLAG_FUSED_GRADIENT on a grid size of the hand-written transforms when it is more than nplanes).  The windows of all
+ * ranks partition [0, grid_size): cuts[r] is the first plane of rank r's window, cuts[ranks] = grid_size.  Then
+ *   pm_slab_deposit writes the window's planes and the one above (pm_slab_planes PM_SLAB_ZSPECTRUM, planes 0 .. window);
+ *     the caller sends each to the rank whose slab holds it, where it is copied or added into that slab's own
+ *     z-transformed planes (PM_SLAB_MESH_ZSPECTRUM, nplanes planes) -- the window's plane first, then the plane above the
+ *     window before it: a fixed order, so the sums have the same bits whatever the arrival order;
+ *   the transforms run on the slab's planes as before and leave its potential planes (PM_SLAB_MESH_POTENTIAL);
+ *   the caller brings the potential of the window's planes, the one below and the two above into PM_MESH_POTENTIAL
+ *     (planes 0 .. window + 2), and pm_slab_gather_kick_drift sends a particle that leaves the window to the rank whose
+ *     window holds its new cell.
+ * Until pm_slab_set_window is called the window is the slab itself, and the two pairs of buffers are the same memory
+ * when window_planes == nplanes (pm_create_slab).
+ * pm_slab_rekey, after pm_slab_set_window on a context that holds particles: those outside the new window go to the
+ * outbox like the leavers of a drift (pm_slab_outbox* and pm_slab_inbox follow).  pm_slab_plane_counts ADDS the number
+ * of live particles in every mesh plane to grid_size uint64 counters in device memory (summed over the ranks, they are
+ * what the caller cuts the windows by).  pm_slab_window reports the present window and the room for it. */
+pm_ctx *pm_create_slab_windowed(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags,
+                                int plane0, int nplanes, int window_planes);
+int pm_slab_set_window(pm_ctx *ctx, const int *cuts, int ranks, int rank);
+int pm_slab_window(const pm_ctx *ctx, int *plane0, int *nplanes, int *max_planes);
+int pm_slab_rekey(pm_ctx *ctx);
+/* The part of a window that lies in the context's own slab needs no exchange: to_mesh != 0 copies (add == 0) or adds
+ * z-transformed planes [first, first + count) of the window's deposit into the slab's planes from mesh_first on;
+ * to_mesh == 0 copies the slab's potential planes [mesh_first, mesh_first + count) to planes first ... of the window's
+ * potential buffer. */
+int pm_slab_copy_planes(pm_ctx *ctx, int to_mesh, int first, int mesh_first, int count, int add);
+int pm_slab_plane_counts(pm_ctx *ctx, uint64_t *device_counts);
+/* pm_generate for a slab context: every rank draws the whole set (a particle's draw depends on its number only) and
+ * keeps the particles whose cell lies in its window, in the order of their numbers, which become their ids.
+ * pm_generate_plane_counts needs no context: it draws the same set on `device` without keeping anything and writes the
+ * number of particles in every mesh plane to host_counts (grid_size entries), so that every rank can compute the same
+ * windows before it makes its context, without a collective (errors: pm_last_error(NULL)). */
+int pm_generate_plane_counts(int device, int grid_size, double box_size, int kind, int64_t n, uint64_t seed, const double *params, int nparams,
+                             int64_t *host_counts);
 /* main.py:25-33 for one slab: host (n,3) float32 positions and velocities, masses (or NULL), and the
  * particles' numbers in the whole run (or NULL for 0..n-1), which travel with them between slabs. */
 int pm_slab_set_particles(pm_ctx *ctx, const float *pos, const float *vel, const float *mass, const uint32_t *ids, int64_t n);
@@ -323,6 +364,7 @@ int pm_set_flags(pm_ctx *ctx, unsigned flags);
  * stream, and the pm_slab_* calls that fill or read caller-owned device buffers no longer wait for the device. */
 int pm_set_stream(pm_ctx *ctx, void *hip_stream);
 int pm_synchronize(pm_ctx *ctx);
+/* particles the context holds (a slab: without those that left in the last drift and have been taken from the outbox) */
 int64_t pm_num_particles(const pm_ctx *ctx);
 const char *pm_last_error(const pm_ctx *ctx);
 

@@ -167,7 +167,8 @@ static int create_impl(pm_ctx *c)
 {
     const int G = c->g.G;
     const size_t M = (size_t)c->g.M, cap = (size_t)c->cap;
-    const size_t plane = (size_t)G * G, planes = (size_t)c->g.Gs;    // a slab context holds its own planes only
+    // a slab context holds the planes of its window only (and those of its slab, where the two may differ)
+    const size_t plane = (size_t)G * G, planes = (size_t)(c->slab ? c->wmax : c->g.Gs);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, pm_noalloc_prepare(c->device));     // set-up for pm_energies_noalloc, which may not do it under a capture
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -209,6 +210,12 @@ static int create_impl(pm_ctx *c)
         for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
     // (a slab's deposit may leave its nplanes + 1 planes as z-transformed rows: one more plane of spectrum)
     TRY(dalloc(c, &c->spectrum, (planes + (c->slab ? 1 : 0)) * G * c->g.Ghp));
+    c->mesh_spec = c->spectrum; c->mesh_pot = c->potential + (c->slab ? plane : 0);
+    if (c->slab && c->wmax != c->slabn) {
+        c->mesh_spec = nullptr; c->mesh_pot = nullptr;
+        TRY(dalloc(c, &c->mesh_spec, (size_t)c->slabn * G * c->g.Ghp));
+        TRY(dalloc(c, &c->mesh_pot, (size_t)c->slabn * plane));
+    }
     TRY(dalloc(c, &c->forces, 3 * cap));
     TRY(dalloc(c, &c->diag, 2 * 1024 + 4));
     HIP_TRY(c, hipMalloc(&c->stage, cap * 32 + 16));
@@ -242,11 +249,12 @@ static int create_impl(pm_ctx *c)
 }
 
 // A context for planes [plane0, plane0 + nplanes) of the mesh: all of them (pm_create) or a slab (pm_create_slab).
-pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab)
+pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab, int window_planes)
 {
-    // cell keys are 32-bit: one key per cell of the planes this context owns, and one more
-    if (grid_size < 2 || nplanes < 1 || (int64_t)nplanes * grid_size * grid_size + 1 >= ((int64_t)1 << 32)) {
-        fail(nullptr, PM_EINVAL, slab ? "nplanes * grid_size^2 must be below 2^32 (cell keys are 32-bit)" : "grid_size must be in [2, 1625] (cell keys are 32-bit)");
+    // cell keys are 32-bit: one key per cell of the planes this context's particles may lie in, and one more
+    if (grid_size < 2 || nplanes < 1 || window_planes < nplanes || (int64_t)window_planes * grid_size * grid_size + 1 >= ((int64_t)1 << 32)) {
+        fail(nullptr, PM_EINVAL, slab ? "the planes of a slab (or of its particle window) times grid_size^2 must be below 2^32 (cell keys are 32-bit)"
+                                      : "grid_size must be in [2, 1625] (cell keys are 32-bit)");
         return nullptr;
     }
     if (!(box_size > 0.0) || !std::isfinite(box_size)) { fail(nullptr, PM_EINVAL, "box_size must be positive and finite"); return nullptr; }
@@ -269,6 +277,7 @@ pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int
     c->slab = slab;
     c->nslabs = grid_size / nplanes;
     c->g.i0 = plane0; c->g.Gs = nplanes; c->g.Gd = slab ? nplanes + 1 : grid_size; c->g.lo = slab ? 1 : 0;
+    c->slab0 = plane0; c->slabn = nplanes; c->wmax = window_planes;
     c->g.sb = (c->fft_custom && !slab) ? pm_fft_spectrum_interleave(grid_size) : 0;
     c->device = device; c->flags = flags; c->cap = n_capacity > 0 ? n_capacity : 1;
     // (for tests: sets smaller than a million particles gain nothing from it, but every test of the path can then run on
@@ -290,7 +299,8 @@ extern "C" {
 
 const char *pm_last_error(const pm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int64_t pm_num_particles(const pm_ctx *ctx) { return ctx ? ctx->n : -1; }
+// (a slab's leavers keep their slots until the next binning: they are not counted)
+int64_t pm_num_particles(const pm_ctx *ctx) { return ctx ? ctx->n - ctx->leaving : -1; }
 
 void pm_destroy(pm_ctx *c)
 {
@@ -301,6 +311,8 @@ void pm_destroy(pm_ctx *c)
     hipFree(c->frac); hipFree(c->elog);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
     hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src);
+    if (c->slab && c->wmax != c->slabn) { hipFree(c->mesh_spec); hipFree(c->mesh_pot); }      // (else they alias spectrum / potential)
+    hipFree(c->cuts);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
     for (int d = 0; d < 3; ++d) hipFree(c->grad[d]);
     hipFree(c->fft_work); hipFree(c->forces); hipFree(c->stage); hipFree(c->diag); hipFree(c->density64);
@@ -339,7 +351,7 @@ void pm_destroy(pm_ctx *c)
 
 pm_ctx *pm_create(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags)
 {
-    return pm_create_planes(grid_size, box_size, n_capacity, device, flags, 0, grid_size, false);
+    return pm_create_planes(grid_size, box_size, n_capacity, device, flags, 0, grid_size, false, grid_size);
 }
 
 int pm_set_stream(pm_ctx *c, void *hip_stream)
@@ -397,13 +409,11 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
     return PM_OK;
 }
 
-int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params, int nparams)
+static int check_generate(pm_ctx *c, int kind, int64_t n, const double *params, int nparams)
 {
-    if (!c) return PM_EINVAL;
-    if (c->slab) return fail(c, PM_ESTATE, "pm_generate fills a whole-mesh context: a slab takes its share through pm_slab_set_particles");
     const int want = pm_generate_param_count(kind);
     if (want < 0) return fail(c, PM_EINVAL, "kind must be PM_IC_UNIFORM, PM_IC_TWO_GALAXY or PM_IC_DISK");
-    if (n < 0 || n > c->cap) return fail(c, PM_EINVAL, "n outside [0, n_capacity]");
+    if (n < 0) return fail(c, PM_EINVAL, "n < 0");
     if (!params || nparams != want) return fail(c, PM_EINVAL, "this kind takes " + std::to_string(want) + " parameters");
     for (int k = 0; k < want; ++k)
         if (!std::isfinite(params[k])) return fail(c, PM_EINVAL, "parameter " + std::to_string(k) + " is not finite");
@@ -412,16 +422,77 @@ int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *par
     for (int k = 0; k < npos; ++k)
         if (!(params[k] > 0.0)) return fail(c, PM_EINVAL, "parameter " + std::to_string(k) + " (a length) must be positive");
     if (params[want - 1] < 0.0) return fail(c, PM_EINVAL, "sigma_v must not be negative");
+    return PM_OK;
+}
+
+int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params, int nparams)
+{
+    if (!c) return PM_EINVAL;
+    TRY(check_generate(c, kind, n, params, nparams));
+    if (!c->slab && n > c->cap) return fail(c, PM_EINVAL, "n outside [0, n_capacity]");
+    if (c->slab && n >= ((int64_t)1 << 32)) return fail(c, PM_EINVAL, "particle numbers travel as 32-bit ids: n must be below 2^32");
+    if (c->slab && c->outbox_pending) return fail(c, PM_ESTATE, "the outbox of the last drift has not been taken yet");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pos_in_f64 = c->pos_f64 = false;
     c->vel_f64 = false;
     TRY(alloc_particles(c));
     // (a set large enough to be binned from the order before: its buffers now, not inside the first step that wants them)
-    if (n >= c->rebin_min && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
-    c->n = n; c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
-    HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((c->slab ? c->cap : n) >= c->rebin_min && !(c->flags & (PM_FLAG_FULL_SORT | PM_FLAG_F64 | PM_FLAG_NGP))) TRY(prepare_rebin(c));
+    c->cur = 0; c->vcur = 0; c->v_stale = false; c->binned = false; c->have_forces = false; c->have_forces64 = false; c->keys_fresh = false; c->order_known = false;
+    if (!c->slab) {
+        c->n = n;
+        HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return PM_OK;
+    }
+    // a slab: every rank draws all n numbers and keeps the particles of its window, in the order of their numbers --
+    // how many each block of 256 numbers keeps, the running sum of that (on the host: a few megabytes, once), the records
+    c->n = 0; c->leaving = 0; c->slab_check = false;
+    const size_t blocks = (size_t)((n + 255) / 256);
+    if (blocks == 0) return PM_OK;
+    uint32_t *dcount = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&dcount, blocks * sizeof(uint32_t)));
+    std::vector<uint32_t> h(blocks);
+    int rc = PM_OK;
+    hipError_t e = pm_launch_generate_count(c, kind, n, seed, params, dcount);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), dcount, blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    uint64_t total = 0;
+    if (e == hipSuccess) {
+        for (size_t b = 0; b < blocks; ++b) { const uint32_t k = h[b]; h[b] = (uint32_t)total; total += k; }
+        if ((int64_t)total > c->cap)
+            rc = fail(c, PM_ENOMEM, std::to_string(total) + " particles of the set lie in this slab's window, its capacity is " + std::to_string(c->cap));
+    }
+    if (e == hipSuccess && rc == PM_OK) e = hipMemcpyAsync(dcount, h.data(), blocks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && rc == PM_OK) e = pm_launch_generate_keep(c, kind, n, seed, params, dcount);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dcount);
+    if (e != hipSuccess) return fail(c, PM_EHIP, std::string("pm_generate: ") + hipGetErrorString(e));
+    if (rc != PM_OK) return rc;
+    c->n = (int64_t)total;
+    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, (size_t)(2 + c->nslabs) * sizeof(uint32_t), c->stream));
+    return PM_OK;
+}
+
+int pm_generate_plane_counts(int device, int grid_size, double box_size, int kind, int64_t n, uint64_t seed, const double *params, int nparams,
+                             int64_t *host_counts)
+{
+    if (grid_size < 2 || grid_size > 16384 || !(box_size > 0.0) || !std::isfinite(box_size)) return fail(nullptr, PM_EINVAL, "grid_size must be in [2, 16384] and box_size positive");
+    TRY(check_generate(nullptr, kind, n, params, nparams));
+    if (!host_counts) return fail(nullptr, PM_EINVAL, "host_counts is NULL");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    pm_geom g{};
+    g.G = grid_size; g.L = box_size; g.inv = (double)grid_size / box_size; g.Lf = (float)box_size; g.Gs = grid_size; g.Gd = grid_size;
+    const size_t G = (size_t)grid_size;
+    unsigned long long *d = nullptr;
+    HIP_TRY(nullptr, hipMalloc((void **)&d, G * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, G * sizeof(unsigned long long));
+    if (e == hipSuccess) e = pm_launch_generate_planes(g, nullptr, kind, n, seed, params, d);
+    static_assert(sizeof(unsigned long long) == sizeof(int64_t), "the counters are copied out as they are");
+    if (e == hipSuccess) e = hipMemcpy(host_counts, d, G * sizeof(int64_t), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, PM_EHIP, std::string("pm_generate_plane_counts: ") + hipGetErrorString(e));
     return PM_OK;
 }
 

@@ -9,6 +9,7 @@
 // the counter, so a set is a pure function of (kind, n, seed, parameters) whatever the launch shape.
 #include "pm_internal.hpp"
 #include "pm_philox_dev.hpp"
+#include "pm_cell_dev.hpp"
 
 namespace {
 
@@ -32,12 +33,11 @@ struct ic_params { double p[16]; };
 
 constexpr double TWO_PI = 6.283185307179586476925286766559;
 
+// particle number idx of the set (kind, n, seed, q): its records
 // purposes (third counter word): 0 radius / position, 1 velocity, 2 height of the disk
-__global__ void __launch_bounds__(BLOCK)
-k_generate(pm_prec<float> *__restrict__ P, pm_vrec<float> *__restrict__ V, int64_t n, int kind, uint64_t seed, ic_params q, pm_geom g)
+__device__ __forceinline__ void draw_particle(int64_t idx, int64_t n, int kind, uint64_t seed, const ic_params &q, const pm_geom &g,
+                                              pm_prec<float> &p, pm_vrec<float> &v)
 {
-    const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= n) return;
     const draw_t draw{(uint32_t)idx, (uint32_t)((uint64_t)idx >> 32), (uint32_t)seed, (uint32_t)(seed >> 32)};
     double x, y, z, sigma, bx = 0.0, by = 0.0, bz = 0.0;     // position, velocity dispersion, bulk velocity
     if (kind == PM_IC_UNIFORM) {
@@ -88,14 +88,74 @@ k_generate(pm_prec<float> *__restrict__ P, pm_vrec<float> *__restrict__ V, int64
     const u32x4 b = draw(1, 0);
     const double m0 = sqrt(-2.0 * log(unit(b.v[0]))), a0 = TWO_PI * unit(b.v[1]);
     const double m1 = sqrt(-2.0 * log(unit(b.v[2]))), a1 = TWO_PI * unit(b.v[3]);
-    pm_prec<float> p;
     p.x = wrap32((float)x, g.Lf); p.y = wrap32((float)y, g.Lf); p.z = wrap32((float)z, g.Lf);
     p.m = 1.0f;
-    pm_vrec<float> v;
     v.x = (float)(bx + sigma * (m0 * cos(a0))); v.y = (float)(by + sigma * (m0 * sin(a0))); v.z = (float)(bz + sigma * (m1 * cos(a1)));
     v.id = (uint32_t)idx;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_generate(pm_prec<float> *__restrict__ P, pm_vrec<float> *__restrict__ V, int64_t n, int kind, uint64_t seed, ic_params q, pm_geom g)
+{
+    const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    pm_prec<float> p;
+    pm_vrec<float> v;
+    draw_particle(idx, n, kind, seed, q, g, p, v);
     P[idx] = p;
     V[idx] = v;
+}
+
+// plane of the mesh a position lies in (functions.py:27-39, float64 like the particle kernels)
+__device__ __forceinline__ int plane_of(float x, const pm_geom &g) { return pmcell::locate((double)x, 0.0, 0.0, g).i; }
+
+// A slab keeps the particles of the set whose cell lies in its window [g.i0, g.i0 + g.Gs), in the order of their numbers:
+// MODE 0 counts them per block of BLOCK numbers, MODE 1 writes them, block b's from slot block_first[b] on.
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK)
+k_generate_window(pm_prec<float> *__restrict__ P, pm_vrec<float> *__restrict__ V, int64_t n, int kind, uint64_t seed, ic_params q, pm_geom g,
+                  uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_first)
+{
+    __shared__ uint32_t wave_keeps[BLOCK / 64];
+    const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    pm_prec<float> p{};
+    pm_vrec<float> v{};
+    bool keep = false;
+    if (idx < n) {
+        draw_particle(idx, n, kind, seed, q, g, p, v);
+        const int il = plane_of(p.x, g) - g.i0;
+        keep = g.Gs == g.G || (il >= 0 && il < g.Gs);
+    }
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wave_keeps[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int k = 0; k < BLOCK / 64; ++k) { if (k < w) before += wave_keeps[k]; total += wave_keeps[k]; }
+    if (MODE == 0) {
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+    } else if (keep) {
+        const uint32_t slot = block_first[blockIdx.x] + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        P[slot] = p;
+        V[slot] = v;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_generate_planes(int64_t n, int kind, uint64_t seed, ic_params q, pm_geom g, unsigned long long *__restrict__ counts)
+{
+    extern __shared__ uint32_t planes[];                // G counters
+    for (int k = threadIdx.x; k < g.G; k += BLOCK) planes[k] = 0u;
+    __syncthreads();
+    for (int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * BLOCK) {
+        pm_prec<float> p;
+        pm_vrec<float> v;
+        draw_particle(idx, n, kind, seed, q, g, p, v);
+        atomicAdd(planes + plane_of(p.x, g), 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < g.G; k += BLOCK)
+        if (planes[k]) atomicAdd(counts + k, (unsigned long long)planes[k]);
 }
 
 }  // namespace
@@ -112,5 +172,37 @@ hipError_t pm_launch_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, con
     ic_params q{};
     for (int k = 0; k < pm_generate_param_count(kind); ++k) q.p[k] = params[k];
     k_generate<<<dim3((unsigned)((n + BLOCK - 1) / BLOCK)), BLOCK, 0, c->stream>>>(c->pf[c->cur], c->vf[c->vcur], n, kind, seed, q, c->g);
+    return hipGetLastError();
+}
+
+static ic_params params_of(int kind, const double *params)
+{
+    ic_params q{};
+    for (int k = 0; k < pm_generate_param_count(kind); ++k) q.p[k] = params[k];
+    return q;
+}
+
+hipError_t pm_launch_generate_count(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params, uint32_t *block_counts)
+{
+    if (n == 0) return hipSuccess;
+    k_generate_window<0><<<dim3((unsigned)((n + BLOCK - 1) / BLOCK)), BLOCK, 0, c->stream>>>(nullptr, nullptr, n, kind, seed, params_of(kind, params), c->g,
+                                                                                             block_counts, nullptr);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_generate_keep(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params, const uint32_t *block_first)
+{
+    if (n == 0) return hipSuccess;
+    k_generate_window<1><<<dim3((unsigned)((n + BLOCK - 1) / BLOCK)), BLOCK, 0, c->stream>>>(c->pf[c->cur], c->vf[c->vcur], n, kind, seed,
+                                                                                             params_of(kind, params), c->g, nullptr, block_first);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_generate_planes(const pm_geom &g, hipStream_t stream, int kind, int64_t n, uint64_t seed, const double *params,
+                                     unsigned long long *plane_counts)
+{
+    if (n == 0) return hipSuccess;
+    const int64_t want = (n + BLOCK - 1) / BLOCK;
+    k_generate_planes<<<(unsigned)(want < 8192 ? want : 8192), BLOCK, (size_t)g.G * sizeof(uint32_t), stream>>>(n, kind, seed, params_of(kind, params), g, plane_counts);
     return hipGetLastError();
 }

@@ -163,6 +163,15 @@ struct pm_ctx {
     // slab decomposition (pm_create_slab)
     bool slab = false;
     int nslabs = 1;
+    // A slab context transforms mesh planes [slab0, slab0 + slabn) -- that never changes -- and holds the particles whose cell
+    // lies in a WINDOW of planes [g.i0, g.i0 + g.Gs), which is the slab itself unless pm_slab_set_window said otherwise
+    // (contexts made with room for wmax > slabn planes).  The deposit writes the window's planes (spectrum / density), the
+    // gather reads the window's potential planes; mesh_spec and mesh_pot are the slab's own z-transformed planes and
+    // potential planes, which alias the window's buffers when the context has no room for any other window.
+    int slab0 = 0, slabn = 0, wmax = 0;
+    float2 *mesh_spec = nullptr;        // slabn planes of the half spectrum (== spectrum when wmax == slabn)
+    float *mesh_pot = nullptr;          // slabn planes of the potential (== potential + one plane when wmax == slabn)
+    int *cuts = nullptr;                // device: nslabs + 1 first planes of the ranks' windows (cuts[nslabs] = G)
     bool y_in_exchange = false;         // hand-written transforms: the passes along y read / write the all-to-all buffer themselves
     bool slab_check = false;            // the next deposit verifies that every particle lies in the slab
     bool outbox_pending = false;        // a drift has run and its leavers have not been taken out yet (pm_slab_outbox*)
@@ -215,7 +224,8 @@ size_t pm_heavy_row_entries(int G, int64_t cap);
 size_t pm_max_units(int64_t cap);
 
 void pm_set_create_error(const std::string &msg);
-pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab);   // what pm_last_error(NULL) reports
+// (window_planes: the most planes a slab's particle window may span; nplanes for a context whose window is its slab)
+pm_ctx *pm_create_planes(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes, bool slab, int window_planes);
 
 // ---- launchers (each enqueues on ctx->stream and returns a hipError_t) ----------------------
 // stage -> records: positions (n,3) of the given dtype + masses (or ones), velocities (or zeros) + iota ids
@@ -223,6 +233,14 @@ hipError_t pm_launch_pack(pm_ctx *c, const void *pos_aos, const float *mass, con
 hipError_t pm_launch_cell_keys(pm_ctx *c);
 // synthetic sets drawn on the device into the live float32 records; the number of parameters a kind takes (-1: no such kind)
 hipError_t pm_launch_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params);
+// the same set, of which a slab context keeps the particles whose cell lies in its window (in the order of their numbers):
+// counts per block of 256 numbers -> (the caller scans them) -> the records; and the particles per mesh plane of the whole set
+hipError_t pm_launch_generate_count(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params, uint32_t *block_counts);
+hipError_t pm_launch_generate_keep(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *params, const uint32_t *block_first);
+hipError_t pm_launch_generate_planes(const pm_geom &g, hipStream_t stream, int kind, int64_t n, uint64_t seed, const double *params,
+                                     unsigned long long *plane_counts);
+hipError_t pm_launch_plane_counts(pm_ctx *c, unsigned long long *plane_counts);      // live particles per mesh plane (adds to the G counters)
+hipError_t pm_launch_rekey(pm_ctx *c);         // key_in of every live particle under the present window; those outside it go to the outbox
 int pm_generate_param_count(int kind);
 hipError_t pm_sort_pairs(pm_ctx *c, int bits);          // key_in -> key_out (sorted), src (storage slot of each sorted entry)
 // the same from the cell order of the step before (key_out, row_start) and the new keys (key_in); key_out / key_alt swap

@@ -121,8 +121,8 @@ hipError_t pm_launch_green_t(pm_ctx *c, float2 *spec_t, int y0, int ny)
 
 hipError_t pm_launch_transpose_pack(pm_ctx *c, const float2 *in, float2 *out, bool unpack)
 {
-    int64_t total = (int64_t)c->g.Gs * c->g.G * c->g.Ghp;
-    k_transpose_blocks<<<dim3((unsigned)((total + BLOCK - 1) / BLOCK)), BLOCK, 0, c->stream>>>(in, out, c->g.Gs, c->g.G, c->g.Ghp, unpack);
+    int64_t total = (int64_t)c->slabn * c->g.G * c->g.Ghp;        // the slab's own planes
+    k_transpose_blocks<<<dim3((unsigned)((total + BLOCK - 1) / BLOCK)), BLOCK, 0, c->stream>>>(in, out, c->slabn, c->g.G, c->g.Ghp, unpack);
     return hipGetLastError();
 }
 

@@ -782,7 +782,54 @@ __device__ constexpr int DI[8] = {0, 1, 0, 0, 1, 1, 0, 1}, DJ[8] = {0, 0, 1, 0, 
 // Where the particles that leave a slab go (SLAB instantiation of k_gather only).
 // count[0]: entries of the outbox, count[1]: entries that did not fit, count[2 + d]: entries bound for slab d,
 // count[2 + nslabs]: set (and never cleared) once a particle was found in a slab that does not own its cell
-struct outbox_t { pm_migrant *rec; uint64_t *key; uint32_t *count; uint32_t cap; };
+// cuts[0 .. nranks]: first plane of every rank's window of planes (cuts[nranks] = G): a leaver goes to the rank whose window
+// holds its new cell
+struct outbox_t { pm_migrant *rec; uint64_t *key; uint32_t *count; uint32_t cap; const int *cuts; int nranks; };
+
+// the rank r with cuts[r] <= plane < cuts[r + 1]
+__device__ __forceinline__ uint32_t rank_of_plane(const outbox_t &ob, int plane)
+{
+    int lo = 0, hi = ob.nranks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ob.cuts[mid] <= plane) lo = mid; else hi = mid - 1;
+    }
+    return (uint32_t)lo;
+}
+
+// A wave's leavers (`leaves`: this lane's particle goes; cn_i: plane of its new cell) into the outbox: one counter update
+// per wave for the slots, one per wave and destination for the counts.
+__device__ __forceinline__ void put_in_outbox(const outbox_t &ob, bool leaves, int cn_i, const pm_migrant &m)
+{
+    const unsigned long long lm = __ballot(leaves);
+    if (!lm) return;
+    const int leader = __ffsll((long long)lm) - 1;
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(ob.count, (uint32_t)__popcll(lm));
+    base = __shfl(base, leader);
+    uint32_t dest = 0;
+    bool kept = false;
+    if (leaves) {
+        dest = rank_of_plane(ob, cn_i);
+        const uint32_t slot = base + (uint32_t)__popcll(lm & ((1ull << lane_id()) - 1ull));
+        kept = slot < ob.cap;
+        if (kept) {
+            ob.rec[slot] = m;
+            ob.key[slot] = ((uint64_t)dest << 32) | m.id;
+        } else {
+            atomicAdd(ob.count + 1, 1u);
+        }
+    }
+    // how many go where: one counter update per wave and destination (a wave's leavers mostly share one)
+    unsigned long long todo = __ballot(kept);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t d = (uint32_t)__shfl((int)dest, first);
+        const unsigned long long same = __ballot(kept && dest == d);
+        if (lane_id() == first) atomicAdd(ob.count + 2 + d, (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
 
 // SLAB: the context owns planes [i0, i0 + Gs) of the mesh; phi holds them with one plane below and two
 // above (plane a of the mesh is plane a - i0 + 1 of the buffer, modulo G), and a particle whose new
@@ -815,7 +862,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
         // it with the next counts -- and read against the slab's first plane, so that no access leaves the buffers.
         const int il = c.i - g.i0;
         if (g.Gs != G && (il < 0 || il >= g.Gs)) {
-            atomicOr(ob.count + 2 + G / g.Gs, 1u);
+            atomicOr(ob.count + 2 + ob.nranks, 1u);
             c.i = g.i0;
         }
     }
@@ -946,35 +993,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     }
     if constexpr (SLAB && sizeof(TV) == 4) {
         const bool leaves = kn == (uint32_t)g.Gs * (uint32_t)G * (uint32_t)G;
-        // one counter update per wave
-        const unsigned long long lm = __ballot(leaves);
-        if (lm) {
-            const int leader = __ffsll((long long)lm) - 1;
-            uint32_t base = 0;
-            if (lane_id() == leader) base = atomicAdd(ob.count, (uint32_t)__popcll(lm));
-            base = __shfl(base, leader);
-            const uint32_t dest = (uint32_t)(cn.i / g.Gs);
-            bool kept = false;
-            if (leaves) {
-                const uint32_t slot = base + (uint32_t)__popcll(lm & ((1ull << lane_id()) - 1ull));
-                kept = slot < ob.cap;
-                if (kept) {
-                    ob.rec[slot] = pm_migrant{o.x, o.y, o.z, o.m, v.x, v.y, v.z, v.id};
-                    ob.key[slot] = ((uint64_t)dest << 32) | v.id;
-                } else {
-                    atomicAdd(ob.count + 1, 1u);
-                }
-            }
-            // how many go where: one counter update per wave and destination (a wave's leavers mostly share one)
-            unsigned long long todo = __ballot(kept);
-            while (todo) {
-                const int first = __ffsll((long long)todo) - 1;
-                const uint32_t d = (uint32_t)__shfl((int)dest, first);
-                const unsigned long long same = __ballot(kept && dest == d);
-                if (lane_id() == first) atomicAdd(ob.count + 2 + d, (uint32_t)__popcll(same));
-                todo &= ~same;
-            }
-        }
+        put_in_outbox(ob, leaves, cn.i, pm_migrant{o.x, o.y, o.z, o.m, v.x, v.y, v.z, v.id});
     }
 }
 
@@ -1005,6 +1024,40 @@ __global__ void k_outbox_offsets(const uint64_t *__restrict__ key, uint32_t coun
         if (key[mid] < target) lo = mid + 1; else hi = mid;
     }
     offsets[d] = lo;
+}
+
+// After the window of a slab has changed: the key of every live particle under the new window; the particles outside
+// it go to the outbox, and get the key that sorts them behind the rest, like the leavers of a drift.
+__global__ void k_rekey(const pm_prec<float> *__restrict__ P, const pm_vrec<float> *__restrict__ V, uint32_t *__restrict__ key, int64_t n,
+                        pm_geom g, outbox_t ob)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = r < n;
+    pm_prec<float> p{};
+    pm_vrec<float> v{};
+    cell_t c{};
+    bool leaves = false;
+    if (live) {
+        p = P[r]; v = V[r];
+        c = locate(p, g);
+        const uint32_t k = cell_key(c, g);
+        key[r] = k;
+        leaves = g.Gs != g.G && k == (uint32_t)g.Gs * (uint32_t)g.G * (uint32_t)g.G;
+    }
+    put_in_outbox(ob, leaves, c.i, pm_migrant{p.x, p.y, p.z, p.m, v.x, v.y, v.z, v.id});
+}
+
+// particles per mesh plane, added to counts[G]
+__global__ void k_plane_counts(const pm_prec<float> *__restrict__ P, int64_t n, pm_geom g, unsigned long long *__restrict__ counts)
+{
+    extern __shared__ uint32_t planes[];                // G counters
+    for (int q = threadIdx.x; q < g.G; q += BLOCK) planes[q] = 0u;
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * BLOCK)
+        atomicAdd(planes + locate(P[r], g).i, 1u);
+    __syncthreads();
+    for (int q = threadIdx.x; q < g.G; q += BLOCK)
+        if (planes[q]) atomicAdd(counts + q, (unsigned long long)planes[q]);
 }
 
 // arrivals behind the live set, with their cell keys
@@ -1223,7 +1276,7 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
         constexpr bool M = decltype(mapped)::value;
         if (c->slab) {
             if constexpr (sizeof(TP) == 4 && sizeof(TV) == 4) {
-                const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap};
+                const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap, c->cuts, c->nslabs};
                 k_gather<float, float, true, true, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces,
                                                                                            c->key_in, n, c->g, dt, integrate, ob, probe);
             }
@@ -1327,6 +1380,22 @@ hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count)
 {
     if (count == 0) return hipSuccess;
     k_append<<<grid_for(count), BLOCK, 0, c->stream>>>(src, c->pf[c->cur], c->vf[c->vcur], c->key_in, c->n, count, c->g);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_rekey(pm_ctx *c)
+{
+    if (c->n == 0) return hipSuccess;
+    const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap, c->cuts, c->nslabs};
+    k_rekey<<<grid_for(c->n), BLOCK, 0, c->stream>>>(c->pf[c->cur], c->vf[c->vcur], c->key_in, c->n, c->g, ob);
+    return hipGetLastError();
+}
+
+hipError_t pm_launch_plane_counts(pm_ctx *c, unsigned long long *plane_counts)
+{
+    if (c->n == 0) return hipSuccess;
+    const int64_t want = (c->n + BLOCK - 1) / BLOCK;
+    k_plane_counts<<<(unsigned)(want < 2048 ? want : 2048), BLOCK, (size_t)c->g.G * sizeof(uint32_t), c->stream>>>(c->pf[c->cur], c->n, c->g, plane_counts);
     return hipGetLastError();
 }
 

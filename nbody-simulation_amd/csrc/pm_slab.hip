@@ -43,6 +43,9 @@ int done(pm_ctx *c)
     return PM_OK;
 }
 
+// with PM_FLAG_TIMING: the launches of a call as one of the single kernels pm_kernel_times reports
+struct kernel_timer : pm_timer { kernel_timer(pm_ctx *c, int k) : pm_timer(c, PM_NSTAGES + k) {} };
+
 int need_slab(pm_ctx *c)
 {
     if (!c) return PM_EINVAL;
@@ -66,7 +69,7 @@ int bits_for(int64_t M)
 // the owned planes, and the 1-D complex transform along x of the transposed spectrum (G, Gs, Ghp).
 int make_plans(pm_ctx *c)
 {
-    const size_t G = (size_t)c->g.G, Gs = (size_t)c->g.Gs, P = (size_t)c->g.Ghp;
+    const size_t G = (size_t)c->g.G, Gs = (size_t)c->slabn, P = (size_t)c->g.Ghp;
     rocfft_plan_description d = nullptr;
     const size_t len2[2] = {G, G};                                  // fastest axis first
     size_t rs[2] = {1, G}, cs[2] = {1, P}, off[1] = {0};
@@ -131,7 +134,8 @@ int ensure_binned(pm_ctx *c)
 
 extern "C" {
 
-pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes)
+pm_ctx *pm_create_slab_windowed(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes,
+                                int window_planes)
 {
     if (nplanes < 1 || plane0 < 0 || grid_size % nplanes != 0 || plane0 % nplanes != 0 || plane0 + nplanes > grid_size ||
         (nplanes != grid_size && nplanes + 3 > grid_size)) {
@@ -143,12 +147,24 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
     // PM_FLAG_FUSED_GRADIENT on a slab: the deposit leaves z-transformed rows (hand-written transforms only); the
     // gradient is always taken inside the gather
     if (!pm_fft_custom_supported(grid_size) || (flags & PM_FLAG_ROCFFT_ONLY)) flags &= ~(unsigned)PM_FLAG_FUSED_GRADIENT;
-    pm_ctx *c = pm_create_planes(grid_size, box_size, n_capacity, device, flags, plane0, nplanes, true);
+    if (window_planes != nplanes) {
+        // a window's planes travel to the slabs that transform them as z-transformed planes: the deposit must write those
+        if (!(flags & PM_FLAG_FUSED_GRADIENT)) {
+            pm_set_create_error("pm_create_slab_windowed: a particle window other than the slab needs PM_FLAG_FUSED_GRADIENT on a grid size of the hand-written transforms");
+            return nullptr;
+        }
+        if (window_planes < nplanes || window_planes + 3 > grid_size) {
+            pm_set_create_error("pm_create_slab_windowed: window_planes must be in [nplanes, grid_size - 3]");
+            return nullptr;
+        }
+    }
+    pm_ctx *c = pm_create_planes(grid_size, box_size, n_capacity, device, flags, plane0, nplanes, true, window_planes);
     if (!c) return nullptr;
     c->y_in_exchange = c->fft_custom && (nplanes & (nplanes - 1)) == 0;
     auto setup = [&]() -> int {
         HIP_TRY(c, hipSetDevice(device));
-        c->outbox_cap = c->cap / 4 + 1024;
+        // (when the windows are cut anew, most of a context's particles may leave at once)
+        c->outbox_cap = window_planes != nplanes ? c->cap : c->cap / 4 + 1024;
         HIP_TRY(c, hipMalloc((void **)&c->outbox, (size_t)c->outbox_cap * sizeof(pm_migrant)));
         HIP_TRY(c, hipMalloc((void **)&c->outbox_key, (size_t)c->outbox_cap * sizeof(uint64_t)));
         HIP_TRY(c, hipMalloc((void **)&c->outbox_key2, (size_t)c->outbox_cap * sizeof(uint64_t)));
@@ -158,6 +174,11 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
         HIP_TRY(c, hipMemset(c->outbox_count, 0, outbox_count_bytes(c) + sizeof(uint32_t)));
         c->outbox_tmp_bytes = pm_sort_outbox_tmp_bytes(c->outbox_cap);
         HIP_TRY(c, hipMalloc(&c->outbox_tmp, c->outbox_tmp_bytes + 16));
+        // the windows to begin with: every rank's own slab
+        std::vector<int> cuts((size_t)c->nslabs + 1);
+        for (int r = 0; r <= c->nslabs; ++r) cuts[(size_t)r] = r * nplanes;
+        HIP_TRY(c, hipMalloc((void **)&c->cuts, cuts.size() * sizeof(int)));
+        HIP_TRY(c, hipMemcpy(c->cuts, cuts.data(), cuts.size() * sizeof(int), hipMemcpyHostToDevice));
         if (!c->fft_custom) TRY(make_plans(c));
         return PM_OK;
     };
@@ -167,6 +188,75 @@ pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int d
         return nullptr;
     }
     return c;
+}
+
+pm_ctx *pm_create_slab(int grid_size, double box_size, int64_t n_capacity, int device, unsigned flags, int plane0, int nplanes)
+{
+    return pm_create_slab_windowed(grid_size, box_size, n_capacity, device, flags, plane0, nplanes, nplanes);
+}
+
+// The planes whose particles this context holds from now on: [cuts[rank], cuts[rank + 1]) of cuts[0] = 0 < cuts[1] < ... <
+// cuts[ranks] = G, the windows of all ranks (a particle that leaves the window goes to the rank whose window holds its
+// new cell).  Particles already in the context stay where they are until pm_slab_rekey sorts out which of them still
+// belong here.
+int pm_slab_set_window(pm_ctx *c, const int *cuts, int ranks, int rank)
+{
+    TRY(need_slab(c));
+    if (!cuts || ranks != c->nslabs || rank != c->slab0 / c->slabn) return fail(c, PM_EINVAL, "pm_slab_set_window: cuts of all G / nplanes ranks, and this context's own rank");
+    if (cuts[0] != 0 || cuts[ranks] != c->g.G) return fail(c, PM_EINVAL, "pm_slab_set_window: cuts must run from 0 to grid_size");
+    for (int r = 0; r < ranks; ++r)
+        if (cuts[r + 1] <= cuts[r]) return fail(c, PM_EINVAL, "pm_slab_set_window: every rank needs at least one plane");
+    const int w0 = cuts[rank], wn = cuts[rank + 1] - cuts[rank];
+    if (wn > c->wmax) return fail(c, PM_EINVAL, "pm_slab_set_window: " + std::to_string(wn) + " planes, the context has room for " + std::to_string(c->wmax));
+    if (c->wmax == c->slabn && (w0 != c->slab0 || wn != c->slabn)) return fail(c, PM_ESTATE, "this context's window is its slab: make it with pm_create_slab_windowed");
+    if (c->outbox_pending) return fail(c, PM_ESTATE, "pm_slab_set_window belongs behind the emptying of the outbox");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->cuts, cuts, (size_t)(ranks + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, pm_settle_velocities(c));       // (src belongs to the order of the old window)
+    c->g.i0 = w0; c->g.Gs = wn; c->g.Gd = wn + 1;
+    // cell keys count from the window's first plane: nothing computed for the old window holds
+    c->binned = false; c->keys_fresh = false; c->order_known = false; c->movers_marked = false; c->have_forces = false;
+    return PM_OK;
+}
+
+int pm_slab_window(const pm_ctx *c, int *plane0, int *nplanes, int *max_planes)
+{
+    if (!c || !c->slab) return PM_EINVAL;
+    if (plane0) *plane0 = c->g.i0;
+    if (nplanes) *nplanes = c->g.Gs;
+    if (max_planes) *max_planes = c->wmax;
+    return PM_OK;
+}
+
+// After pm_slab_set_window: the particles whose cell lies outside the new window go to the outbox, as the particles
+// that leave in a drift do (pm_slab_outbox_counts / pm_slab_outbox_records / pm_slab_inbox follow).
+int pm_slab_rekey(pm_ctx *c)
+{
+    TRY(need_slab(c));
+    if (!c->pf[0]) return fail(c, PM_ESTATE, "no particles");
+    if (c->outbox_pending) return fail(c, PM_ESTATE, "the outbox of the last drift has not been taken yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->leaving) TRY(ensure_binned(c));     // (drops the leavers of a drift that are still among the slots)
+    HIP_TRY(c, pm_settle_velocities(c));
+    HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, outbox_count_bytes(c), c->stream));
+    HIP_TRY(c, pm_launch_rekey(c));
+    c->binned = false; c->have_forces = false; c->keys_fresh = true; c->order_known = false; c->movers_marked = false;
+    c->outbox_pending = true;
+    return PM_OK;
+}
+
+// Live particles per mesh plane, ADDED to the grid_size counters at device_counts (uint64): what the windows are cut by.
+int pm_slab_plane_counts(pm_ctx *c, uint64_t *device_counts)
+{
+    if (!c || !device_counts) return PM_EINVAL;
+    if (!c->pf[0]) return fail(c, PM_ESTATE, "no particles");
+    if (c->outbox_pending) return fail(c, PM_ESTATE, "the outbox of the last drift has not been taken yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->leaving) TRY(ensure_binned(c));
+    HIP_TRY(c, pm_launch_plane_counts(c, (unsigned long long *)device_counts));
+    TRY(done(c));
+    return PM_OK;
 }
 
 // pos, vel: host (n,3) float32; mass: host (n) or NULL; ids: host (n) particle numbers of the whole run
@@ -212,22 +302,52 @@ int pm_slab_deposit(pm_ctx *c)
 int pm_slab_planes(pm_ctx *c, int which, int first, int count, void *device_buffer, int op)
 {
     TRY(need_slab(c));
-    const int limit = which == PM_MESH_POTENTIAL ? c->g.Gs + 3 : c->g.Gs + 1;
-    if ((which != PM_MESH_DENSITY && which != PM_MESH_POTENTIAL && which != PM_SLAB_ZSPECTRUM) || first < 0 || count < 0 || first + count > limit ||
-        !device_buffer || op < 0 || op > 2)
+    const bool zs = which == PM_SLAB_ZSPECTRUM || which == PM_SLAB_MESH_ZSPECTRUM;
+    const int limit = which == PM_MESH_POTENTIAL ? c->g.Gs + 3 : (which == PM_SLAB_MESH_ZSPECTRUM || which == PM_SLAB_MESH_POTENTIAL) ? c->slabn : c->g.Gs + 1;
+    if ((which != PM_MESH_DENSITY && which != PM_MESH_POTENTIAL && !zs && which != PM_SLAB_MESH_POTENTIAL) || first < 0 || count < 0 ||
+        first + count > limit || !device_buffer || op < 0 || op > 2)
         return fail(c, PM_EINVAL, "pm_slab_planes: bad mesh, plane range, buffer or op");
-    if (which == PM_SLAB_ZSPECTRUM && !spectral_deposit(c))
+    if (zs && !spectral_deposit(c))
         return fail(c, PM_ESTATE, "pm_slab_planes: this context's deposit writes density planes (PM_MESH_DENSITY), not z-transformed ones");
     if (which == PM_MESH_DENSITY && spectral_deposit(c))
         return fail(c, PM_ESTATE, "pm_slab_planes: this context's deposit writes z-transformed planes (PM_SLAB_ZSPECTRUM), no density mesh");
     HIP_TRY(c, hipSetDevice(c->device));
     // a plane of the half spectrum is G rows of pitch complex64 = 2 G pitch floats (the padding of the rows travels along)
-    const size_t plane = which == PM_SLAB_ZSPECTRUM ? 2 * (size_t)c->g.G * c->g.Ghp : (size_t)c->g.G * c->g.G;
-    float *mesh = (which == PM_MESH_DENSITY ? c->density : which == PM_MESH_POTENTIAL ? c->potential : (float *)c->spectrum) + (size_t)first * plane;
+    const size_t plane = zs ? 2 * (size_t)c->g.G * c->g.Ghp : (size_t)c->g.G * c->g.G;
+    float *base = which == PM_MESH_DENSITY ? c->density : which == PM_MESH_POTENTIAL ? c->potential : which == PM_SLAB_ZSPECTRUM ? (float *)c->spectrum
+                : which == PM_SLAB_MESH_ZSPECTRUM ? (float *)c->mesh_spec : c->mesh_pot;
+    float *mesh = base + (size_t)first * plane;
     const size_t bytes = (size_t)count * plane * sizeof(float);
     if (op == 0) HIP_TRY(c, hipMemcpyAsync(device_buffer, mesh, bytes, hipMemcpyDeviceToDevice, c->stream));
     else if (op == 1) HIP_TRY(c, hipMemcpyAsync(mesh, device_buffer, bytes, hipMemcpyDeviceToDevice, c->stream));
     else HIP_TRY(c, pm_launch_add(c, mesh, (const float *)device_buffer, (int64_t)count * (int64_t)plane));
+    TRY(done(c));
+    return PM_OK;
+}
+
+// Planes between the window's buffers and the slab's own, inside the context: to_mesh != 0 copies (add == 0) or adds
+// z-transformed planes [first, first + count) of the window's deposit to the slab's planes from `mesh_first` on; to_mesh
+// == 0 copies potential planes [mesh_first, ...) of the slab to planes `first` ... of the window's potential buffer.  For
+// the part of a window that lies in the context's own slab, which needs no exchange.
+int pm_slab_copy_planes(pm_ctx *c, int to_mesh, int first, int mesh_first, int count, int add)
+{
+    TRY(need_slab(c));
+    if (count == 0) return PM_OK;
+    if (c->wmax == c->slabn) return fail(c, PM_ESTATE, "pm_slab_copy_planes: this context's window is its slab (the buffers are the same memory)");
+    const int limit = to_mesh ? c->g.Gs + 1 : c->g.Gs + 3;
+    if (first < 0 || count < 0 || first + count > limit || mesh_first < 0 || mesh_first + count > c->slabn)
+        return fail(c, PM_EINVAL, "pm_slab_copy_planes: plane range outside the buffers");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t plane = (size_t)c->g.G * c->g.G, splane = 2 * (size_t)c->g.G * c->g.Ghp;
+    if (to_mesh) {
+        float *dst = (float *)c->mesh_spec + (size_t)mesh_first * splane;
+        const float *src = (const float *)c->spectrum + (size_t)first * splane;
+        if (add) HIP_TRY(c, pm_launch_add(c, dst, src, (int64_t)count * (int64_t)splane));
+        else HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)count * splane * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(c->potential + (size_t)first * plane, c->mesh_pot + (size_t)mesh_first * plane, (size_t)count * plane * sizeof(float),
+                                  hipMemcpyDeviceToDevice, c->stream));
+    }
     TRY(done(c));
     return PM_OK;
 }
@@ -238,22 +358,23 @@ int pm_slab_fft2(pm_ctx *c, int dir)
 {
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t plane = (size_t)c->g.G * c->g.G;
-    float *pot = c->potential + plane;
+    // (the slab's own planes: where the window is the slab, mesh_spec is spectrum and mesh_pot plane 1 of potential)
+    float *pot = c->mesh_pot;
     if (c->fft_custom) {
         // (with y_in_exchange the passes along y belong to pm_slab_pack / pm_slab_unpack)
         if (dir < 0) {
             // (a deposit that writes z-transformed rows has done the transform along z already)
-            if (!spectral_deposit(c)) HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density, nullptr, c->spectrum, c->g.Gs));
-            if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, -1, c->spectrum, c->g.Gs));
+            if (!spectral_deposit(c)) HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density, nullptr, c->mesh_spec, c->slabn));
+            if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, -1, c->mesh_spec, c->slabn));
         } else {
-            if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, 1, c->spectrum, c->g.Gs));
-            HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, pot, c->spectrum, c->g.Gs));
+            if (!c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_planes(c, 1, c->mesh_spec, c->slabn));
+            kernel_timer k(c, PM_KERNEL_ROW_INV);
+            HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, pot, c->mesh_spec, c->slabn));
         }
     } else {
         void *in[1], *out[1];
-        if (dir < 0) { in[0] = c->density; out[0] = c->spectrum; FFT_TRY(c, rocfft_execute(c->slab_fwd2, in, out, c->info)); }
-        else { in[0] = c->spectrum; out[0] = pot; FFT_TRY(c, rocfft_execute(c->slab_inv2, in, out, c->info)); }
+        if (dir < 0) { in[0] = c->density; out[0] = c->mesh_spec; FFT_TRY(c, rocfft_execute(c->slab_fwd2, in, out, c->info)); }
+        else { in[0] = c->mesh_spec; out[0] = pot; FFT_TRY(c, rocfft_execute(c->slab_inv2, in, out, c->info)); }
     }
     TRY(done(c));
     return PM_OK;
@@ -265,8 +386,10 @@ int pm_slab_pack(pm_ctx *c, void *device_blocks)
 {
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->spectrum, (float2 *)device_blocks, c->g.Gs, 0, c->g.Gs));
-    else HIP_TRY(c, pm_launch_transpose_pack(c, c->spectrum, (float2 *)device_blocks, false));
+    if (c->y_in_exchange) {
+        kernel_timer k(c, PM_KERNEL_COL_Y_FWD);
+        HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->mesh_spec, (float2 *)device_blocks, c->slabn, 0, c->slabn));
+    } else HIP_TRY(c, pm_launch_transpose_pack(c, c->mesh_spec, (float2 *)device_blocks, false));
     TRY(done(c));
     return PM_OK;
 }
@@ -275,8 +398,10 @@ int pm_slab_unpack(pm_ctx *c, const void *device_blocks)
 {
     TRY(need_slab(c));
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->y_in_exchange) HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs, 0, c->g.Gs));
-    else HIP_TRY(c, pm_launch_transpose_pack(c, (const float2 *)device_blocks, c->spectrum, true));
+    if (c->y_in_exchange) {
+        kernel_timer k(c, PM_KERNEL_COL_Y_INV);
+        HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->mesh_spec, (float2 *)device_blocks, c->slabn, 0, c->slabn));
+    } else HIP_TRY(c, pm_launch_transpose_pack(c, (const float2 *)device_blocks, c->mesh_spec, true));
     TRY(done(c));
     return PM_OK;
 }
@@ -289,7 +414,7 @@ static int planes_in_turn(pm_ctx *c, int first, int count)
     TRY(need_slab(c));
     if (!(c->fft_custom && c->y_in_exchange))
         return fail(c, PM_ESTATE, "plane-by-plane transforms need the hand-written transforms and a power-of-two number of planes: use pm_slab_fft2 with pm_slab_pack / pm_slab_unpack");
-    if (first < 0 || count < 0 || first + count > c->g.Gs) return fail(c, PM_EINVAL, "plane range outside the slab");
+    if (first < 0 || count < 0 || first + count > c->slabn) return fail(c, PM_EINVAL, "plane range outside the slab");
     return PM_OK;
 }
 
@@ -300,8 +425,11 @@ int pm_slab_forward_planes(pm_ctx *c, void *device_blocks, int first, int count)
     if (count == 0) return PM_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t plane = (size_t)c->g.G * c->g.G, splane = (size_t)c->g.G * c->g.Ghp;
-    if (!spectral_deposit(c)) HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density + first * plane, nullptr, c->spectrum + first * splane, count));
-    HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->spectrum, (float2 *)device_blocks, c->g.Gs, first, count));
+    if (!spectral_deposit(c)) HIP_TRY(c, pm_launch_row_fft_planes(c, true, c->density + first * plane, nullptr, c->mesh_spec + first * splane, count));
+    {
+        kernel_timer k(c, PM_KERNEL_COL_Y_FWD);
+        HIP_TRY(c, pm_launch_col_fft_blocks(c, -1, c->mesh_spec, (float2 *)device_blocks, c->slabn, first, count));
+    }
     TRY(done(c));
     return PM_OK;
 }
@@ -313,8 +441,14 @@ int pm_slab_inverse_planes(pm_ctx *c, const void *device_blocks, int first, int 
     if (count == 0) return PM_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t plane = (size_t)c->g.G * c->g.G, splane = (size_t)c->g.G * c->g.Ghp;
-    HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->spectrum, (float2 *)device_blocks, c->g.Gs, first, count));
-    HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, c->potential + (1 + first) * plane, c->spectrum + first * splane, count));
+    {
+        kernel_timer k(c, PM_KERNEL_COL_Y_INV);
+        HIP_TRY(c, pm_launch_col_fft_blocks(c, 1, c->mesh_spec, (float2 *)device_blocks, c->slabn, first, count));
+    }
+    {
+        kernel_timer k(c, PM_KERNEL_ROW_INV);
+        HIP_TRY(c, pm_launch_row_fft_planes(c, false, nullptr, c->mesh_pot + first * plane, c->mesh_spec + first * splane, count));
+    }
     TRY(done(c));
     return PM_OK;
 }
@@ -328,11 +462,12 @@ int pm_slab_solve_x(pm_ctx *c, void *device_spectrum_t)
     HIP_TRY(c, hipSetDevice(c->device));
     float2 *s = (float2 *)device_spectrum_t;
     if (c->fft_custom) {
-        HIP_TRY(c, pm_launch_solve_x(c, s, c->g.i0, c->g.Gs));
+        kernel_timer k(c, PM_KERNEL_COL_X_GREEN);
+        HIP_TRY(c, pm_launch_solve_x(c, s, c->slab0, c->slabn));
     } else {
         void *io[1] = {s};
         FFT_TRY(c, rocfft_execute(c->slab_fwdx, io, nullptr, c->info));
-        HIP_TRY(c, pm_launch_green_t(c, s, c->g.i0, c->g.Gs));
+        HIP_TRY(c, pm_launch_green_t(c, s, c->slab0, c->slabn));
         FFT_TRY(c, rocfft_execute(c->slab_invx, io, nullptr, c->info));
     }
     TRY(done(c));
@@ -348,7 +483,10 @@ int pm_slab_gather_kick_drift(pm_ctx *c, double dt)
     if (c->pos_f64 || c->vel_f64) return fail(c, PM_ESTATE, "slab contexts hold float32 particles");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->outbox_count, 0, outbox_count_bytes(c), c->stream));
-    HIP_TRY(c, pm_launch_gather(c, dt, true, false, true));
+    {
+        kernel_timer k(c, PM_KERNEL_GATHER);
+        HIP_TRY(c, pm_launch_gather(c, dt, true, false, true));
+    }
     c->binned = false; c->have_forces = false; c->keys_fresh = true;
     c->outbox_pending = true;       // the leavers are still in the live set until the outbox has been taken
     return PM_OK;
@@ -415,9 +553,12 @@ int pm_slab_inbox(pm_ctx *c, const void *device_records, int64_t n)
     TRY(need_slab(c));
     if (n < 0 || (n > 0 && !device_records)) return fail(c, PM_EINVAL, "bad inbox");
     if (c->outbox_pending) return fail(c, PM_ESTATE, "pm_slab_inbox belongs behind pm_slab_outbox (or pm_slab_outbox_records)");
-    if (c->n + n > c->cap) return fail(c, PM_ENOMEM, "particle capacity exceeded: " + std::to_string(c->n + n) + " > " + std::to_string(c->cap));
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->v_stale) return fail(c, PM_ESTATE, "pm_slab_inbox belongs between the drift and the next deposit");
+    // the leavers keep their slots until the next binning: when the arrivals do not fit beside them (a change of windows
+    // moves most of a context's particles), the binning that drops them runs now
+    if (c->n + n > c->cap && c->leaving > 0) TRY(ensure_binned(c));
+    if (c->n + n > c->cap) return fail(c, PM_ENOMEM, "particle capacity exceeded: " + std::to_string(c->n + n) + " > " + std::to_string(c->cap));
+    if (c->v_stale) HIP_TRY(c, pm_settle_velocities(c));      // (after that binning the velocity records lag behind: the arrivals' go in behind the settled ones)
     HIP_TRY(c, pm_launch_append(c, (const pm_migrant *)device_records, n));
     TRY(done(c));
     c->n += n;

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PM_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libpm.so")
 
 PM_F32, PM_F64 = 0, 1
-MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ, SLAB_ZSPECTRUM = range(6)
+MESH_DENSITY, MESH_POTENTIAL, MESH_GX, MESH_GY, MESH_GZ, SLAB_ZSPECTRUM, SLAB_MESH_ZSPECTRUM, SLAB_MESH_POTENTIAL = range(8)
 FLAG_TIMING, FLAG_FUSED_GRADIENT, FLAG_ROCFFT_ONLY, FLAG_NGP, FLAG_F64, FLAG_FULL_SORT = 1, 2, 4, 8, 32, 64
 IC_KINDS = {"uniform": 0, "two_galaxy": 1, "disk": 2}
 STAGES = ("bin", "deposit", "fft_fwd", "green", "fft_inv", "gradient", "gather")
@@ -57,6 +57,13 @@ SIGNATURES = {
     "pm_forces_f64": (_int, [_c_p]),
     "pm_get_forces_f64": (_int, [_c_p, _c_p]),
     "pm_create_slab": (_c_p, [_int, _dbl, _i64, _int, ctypes.c_uint, _int, _int]),
+    "pm_create_slab_windowed": (_c_p, [_int, _dbl, _i64, _int, ctypes.c_uint, _int, _int, _int]),
+    "pm_slab_set_window": (_int, [_c_p, _c_p, _int, _int]),
+    "pm_slab_window": (_int, [_c_p, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "pm_slab_rekey": (_int, [_c_p]),
+    "pm_slab_copy_planes": (_int, [_c_p, _int, _int, _int, _int, _int]),
+    "pm_slab_plane_counts": (_int, [_c_p, _c_p]),
+    "pm_generate_plane_counts": (_int, [_int, _int, _dbl, _int, _i64, ctypes.c_uint64, _c_p, _int, _c_p]),
     "pm_slab_set_particles": (_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _i64]),
     "pm_slab_deposit": (_int, [_c_p]),
     "pm_slab_planes": (_int, [_c_p, _int, _int, _int, _c_p, _int]),

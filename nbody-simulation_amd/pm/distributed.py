@@ -30,37 +30,123 @@ import torch.distributed as dist
 from . import _lib
 
 
-def slab_of(positions, grid_size, box_size, world):
-    """Rank that owns each particle: plane i of its cell (functions.py:27-39, float64 like numba) // (G / world)."""
+def plane_of(positions, grid_size, box_size):
+    """Plane i of each particle's cell (functions.py:27-39, float64 like numba)."""
     x = np.asarray(positions)[:, 0].astype(np.float64)
     i = ((x % float(box_size)) * (grid_size / float(box_size))).astype(np.int64)
     i[i >= grid_size] -= grid_size
-    return i // (grid_size // world)
+    return i
+
+
+def slab_of(positions, grid_size, box_size, world):
+    """Rank that owns each particle when every rank's particles are those of its slab: plane i of the cell // (G / world)."""
+    return plane_of(positions, grid_size, box_size) // (grid_size // world)
+
+
+def equal_cuts(grid_size, world):
+    """First plane of every rank's window when the windows are the slabs themselves, and G behind them."""
+    return [r * (grid_size // world) for r in range(world + 1)]
+
+
+def balanced_cuts(plane_counts, world, max_planes=None, plane_weight=0.0):
+    """Windows of (nearly) equal particle count: cuts[r] = first plane of rank r's window, cuts[world] = G, from the
+    number of particles in every plane of the mesh.  Rank r's window ends at the plane boundary nearest to r + 1 shares
+    of the particles; every window has at least one plane and at most max_planes.  A plane is not divided, so a plane
+    that holds more than a share of the particles bounds the balance that can be had.
+
+    plane_weight: what a plane of the window costs its rank, in particles -- its rows are deposited, sent to the slab that
+    transforms them and their potential is brought back whether they hold particles or not (measured on 512^3: a plane
+    costs about as much as half the mean number of particles per plane).  The shares are then of particles + plane_weight
+    per plane, so that a rank in the empty outskirts of a clustered set gets fewer particles to make up for its planes."""
+    counts = np.asarray(plane_counts, dtype=np.float64) + float(plane_weight)
+    G = len(counts)
+    wmax = G - 3 if max_planes is None else int(max_planes)
+    if world * wmax < G or world > G:
+        raise ValueError(f"{world} windows of at most {wmax} planes cannot cover {G} planes")
+    before = np.concatenate(([0.0], np.cumsum(counts)))          # before[b]: particles in planes < b
+    cuts = [0]
+    for r in range(1, world):
+        b = int(np.argmin(np.abs(before - before[-1] * r / world)))
+        lo = max(cuts[-1] + 1, G - (world - r) * wmax)            # the ranks after this one can still cover the rest
+        hi = min(cuts[-1] + wmax, G - (world - r))                # ... and have a plane each
+        cuts.append(min(max(b, lo), hi))
+    cuts.append(G)
+    return cuts
+
+
+def owner_by_cuts(positions, grid_size, box_size, cuts):
+    """Rank whose window [cuts[r], cuts[r + 1]) holds the plane of each particle's cell."""
+    return np.searchsorted(np.asarray(cuts), plane_of(positions, grid_size, box_size), side="right") - 1
+
+
+def plane_segments(cuts, grid_size, rank, below, above):
+    """The planes cuts[rank] - below .. cuts[rank + 1] - 1 + above (modulo G) of rank's window and its surroundings, as
+    runs that lie in one slab each: [(t0, count, owner, first)] -- buffer planes t0 .. t0 + count - 1 (t counts from the
+    first of these planes) are planes first .. of the slab of rank `owner`.  The last `above` planes are runs of their
+    own (they are what the deposit adds to other windows' planes)."""
+    world = len(cuts) - 1
+    Gs = grid_size // world
+    w0, wn = cuts[rank], cuts[rank + 1] - cuts[rank]
+    total = below + wn + above
+    segs = []
+    for t in range(total):
+        p = (w0 - below + t) % grid_size
+        owner, first = p // Gs, p % Gs
+        new_run = not segs or segs[-1][2] != owner or segs[-1][3] + segs[-1][1] != first or t == below + wn
+        if new_run:
+            segs.append([t, 1, owner, first])
+        else:
+            segs[-1][1] += 1
+    return [tuple(x) for x in segs]
+
+
+def generated_plane_counts(grid_size, box_size, kind, n, seed=0, device_index=0, **params):
+    """Particles of the synthetic set (kind, n, seed) in every mesh plane (host int64 array of G), drawn on the device without
+    keeping anything (pm_generate_plane_counts): the same on every rank, so that windows can be cut from it before any
+    context is made and without a collective."""
+    from .simulation import ic_parameters
+    lib = _lib.load()
+    arr = np.asarray(ic_parameters(kind, float(box_size), **params), dtype=np.float64)
+    out = np.zeros(int(grid_size), np.int64)
+    rc = lib.pm_generate_plane_counts(int(device_index), int(grid_size), float(box_size), _lib.IC_KINDS[kind], int(n), int(seed) & (2 ** 64 - 1),
+                                      arr.ctypes.data, len(arr), out.ctypes.data)
+    if rc != 0:
+        raise _lib.PMError(f"pm_generate_plane_counts: error {rc}: " + (lib.pm_last_error(None) or b"?").decode())
+    return out
 
 
 class HipSlabEngine:
     """Local stages of one slab on one GPU through libpm.so."""
 
-    def __init__(self, grid_size, box_size, plane0, nplanes, capacity, device_index=0, rocfft_only=False, full_sort=False):
-        """full_sort: PM_FLAG_FULL_SORT (every binning sorts the whole slab; for comparisons)"""
+    def __init__(self, grid_size, box_size, plane0, nplanes, capacity, device_index=0, rocfft_only=False, full_sort=False, window_planes=None):
+        """full_sort: PM_FLAG_FULL_SORT (every binning sorts the whole slab; for comparisons).  window_planes: room for a
+        window of that many planes of particles (pm_create_slab_windowed); None: the particles are those of the slab."""
         self.lib = _lib.load()
         self.G, self.L, self.i0, self.Gs = int(grid_size), float(box_size), int(plane0), int(nplanes)
         self.world = self.G // self.Gs
+        self.rank = self.i0 // self.Gs
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
         self.cap = int(capacity)
         # FLAG_FUSED_GRADIENT on a slab: where the hand-written transforms apply, the deposit writes its planes already
         # transformed along z (no density mesh); elsewhere the flag changes nothing
         flags = _lib.FLAG_FUSED_GRADIENT | (_lib.FLAG_ROCFFT_ONLY if rocfft_only else 0) | (_lib.FLAG_FULL_SORT if full_sort else 0)
-        self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, flags, self.i0, self.Gs)
+        self._flags = flags
+        self.windowed = window_planes is not None and int(window_planes) != self.Gs
+        if self.windowed:
+            self.ctx = self.lib.pm_create_slab_windowed(self.G, self.L, self.cap, device_index, flags, self.i0, self.Gs, int(window_planes))
+        else:
+            self.ctx = self.lib.pm_create_slab(self.G, self.L, self.cap, device_index, flags, self.i0, self.Gs)
         if not self.ctx:
             raise _lib.PMError("pm_create_slab failed: " + (self.lib.pm_last_error(None) or b"?").decode())
+        self.window_planes = int(window_planes) if self.windowed else self.Gs
+        self.w0, self.wn = self.i0, self.Gs                      # the window: the slab until set_window says otherwise
         # the library works on torch's current stream: its kernels, torch's copies and the collectives order themselves
         self._check(self.lib.pm_set_stream(self.ctx, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         self.pitch = self.lib.pm_slab_pitch(self.ctx)
         f32 = dict(dtype=torch.float32, device=self.device)
         self._blocks = [torch.empty((self.Gs * self.G * self.pitch, 2), **f32) for _ in range(2)]
-        self._records = torch.empty((self.cap // 4 + 1024, 8), **f32)
+        self._records = torch.empty((self.cap if self.windowed else self.cap // 4 + 1024, 8), **f32)
         self._counts = torch.zeros(self.world + 1, dtype=torch.int64, device=self.device)
         # what the deposit leaves: z-transformed planes (G rows of `pitch` complex64) or density planes (G rows of G floats)
         probe = torch.empty(2 * self.G * self.pitch, **f32)
@@ -78,6 +164,18 @@ class HipSlabEngine:
         if rc < 0:
             self._check(-rc)
         return bool(rc), int(movers.value)
+
+    def set_timing(self, on):
+        """PM_FLAG_TIMING on the slab's context: HIP events around its kernels (kernel_times)."""
+        flags = (self._flags & (_lib.FLAG_FUSED_GRADIENT | _lib.FLAG_FULL_SORT)) | (_lib.FLAG_TIMING if on else 0)
+        self._check(self.lib.pm_set_flags(self.ctx, flags))
+
+    def kernel_times(self):
+        """{kernel: (milliseconds, launches)} of this slab's context since the last call (pm_kernel_times; needs set_timing(True))"""
+        ms = (ctypes.c_float * len(_lib.KERNELS))()
+        calls = (ctypes.c_int * len(_lib.KERNELS))()
+        self._check(self.lib.pm_kernel_times(self.ctx, ms, calls))
+        return {k: (float(ms[i]), int(calls[i])) for i, k in enumerate(_lib.KERNELS)}
 
     def _check(self, rc):
         _lib.check(self.ctx, rc)
@@ -97,6 +195,63 @@ class HipSlabEngine:
         if len(pos) > self.cap:
             raise ValueError("more particles than the engine's capacity")
         self._check(self.lib.pm_slab_set_particles(self.ctx, pos.ctypes.data, vel.ctypes.data, mass.ctypes.data, ids.ctypes.data, len(pos)))
+
+    def generate(self, kind, n, seed=0, **params):
+        """The particles of the synthetic set (kind, n, seed) whose cell lies in this slab's window, drawn on the device
+        (pm_generate on a slab context: every rank draws every number and keeps its own; ids = the numbers)."""
+        from .simulation import ic_parameters
+        arr = np.asarray(ic_parameters(kind, self.L, **params), dtype=np.float64)
+        self._check(self.lib.pm_generate(self.ctx, _lib.IC_KINDS[kind], int(n), int(seed) & (2 ** 64 - 1), arr.ctypes.data, len(arr)))
+
+    def generate_plane_counts(self, kind, n, seed=0, **params):
+        return generated_plane_counts(self.G, self.L, kind, n, seed, self.device.index or 0, **params)
+
+    # ---- a window of particles apart from the slab (pm_create_slab_windowed) ----
+    def set_window(self, cuts):
+        """cuts: first plane of every rank's window, and G (pm_slab_set_window)."""
+        arr = (ctypes.c_int * len(cuts))(*[int(x) for x in cuts])
+        self._check(self.lib.pm_slab_set_window(self.ctx, arr, len(cuts) - 1, self.rank))
+        self.w0, self.wn = int(cuts[self.rank]), int(cuts[self.rank + 1] - cuts[self.rank])
+
+    def rekey(self):
+        """After set_window: the particles outside the new window go to the outbox (pm_slab_rekey)."""
+        self._check(self.lib.pm_slab_rekey(self.ctx))
+
+    def plane_counts(self):
+        """This slab's live particles in every mesh plane: int64 tensor of G on the device."""
+        out = torch.zeros(self.G, dtype=torch.int64, device=self.device)
+        self._check(self.lib.pm_slab_plane_counts(self.ctx, out.data_ptr()))
+        return out
+
+    @property
+    def deposit_plane_elems(self):
+        """float32 elements of one plane as the deposit leaves it"""
+        return 2 * self.G * self.pitch if self.spectral else self.G * self.G
+
+    def deposit_planes_out(self, first, count):
+        """Planes [first, first + count) of what the deposit wrote (the window's planes, then the one above), flat."""
+        out = torch.empty(count * self.deposit_plane_elems, dtype=torch.float32, device=self.device)
+        which = _lib.SLAB_ZSPECTRUM if self.spectral else _lib.MESH_DENSITY
+        self._check(self.lib.pm_slab_planes(self.ctx, which, int(first), int(count), out.data_ptr(), 0))
+        return out
+
+    def mesh_planes_in(self, first, planes, add):
+        """Copy or add deposit planes (flat) into the slab's own planes [first, ...) -- the input of the transforms."""
+        planes = planes.to(self.device, torch.float32).contiguous()
+        count = planes.numel() // self.deposit_plane_elems
+        self._check(self.lib.pm_slab_planes(self.ctx, _lib.SLAB_MESH_ZSPECTRUM, int(first), int(count), planes.data_ptr(), 2 if add else 1))
+
+    def mesh_potential_out(self, first, count):
+        out = torch.empty(count * self.G * self.G, dtype=torch.float32, device=self.device)
+        self._check(self.lib.pm_slab_planes(self.ctx, _lib.SLAB_MESH_POTENTIAL, int(first), int(count), out.data_ptr(), 0))
+        return out
+
+    def own_deposit_planes(self, first, mesh_first, count, add):
+        """The same for the part of the window that lies in this rank's own slab: one copy inside the context."""
+        self._check(self.lib.pm_slab_copy_planes(self.ctx, 1, int(first), int(mesh_first), int(count), 1 if add else 0))
+
+    def own_potential_planes(self, mesh_first, first, count):
+        self._check(self.lib.pm_slab_copy_planes(self.ctx, 0, int(first), int(mesh_first), int(count), 0))
 
     def set_softening(self, length):
         """Gaussian softening of the solve along x (pm_set_softening); every rank must set the same length."""
@@ -320,6 +475,20 @@ class _Comm:
         dist.all_to_all_single(recv, counts.contiguous(), group=self.group)
         return recv
 
+    def all_reduce_sum(self, t):
+        """Sum of an int64 tensor over the ranks (a new tensor where t lives)."""
+        if self.world == 1 and not (self.always and self.on):
+            return t.clone()
+        if self.stage_on_host and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            return h.to(t.device)
+        if self.backend == "nccl" and not t.is_cuda:
+            return self.all_reduce_sum(t.cuda()).cpu()
+        out = t.clone()
+        dist.all_reduce(out, group=self.group)
+        return out
+
     def barrier(self):
         if self.on:
             dist.barrier(group=self.group)
@@ -391,6 +560,12 @@ class ThreadComm:
         k = counts.numel() // self.world
         return torch.cat(self.all_to_all([counts[p * k:(p + 1) * k] for p in range(self.world)], [k] * self.world))
 
+    def all_reduce_sum(self, t):
+        self._publish(t)
+        out = torch.stack([self._s.slots[p] for p in range(self.world)]).sum(dim=0)
+        self._retire()
+        return out
+
     def barrier(self):
         self._s.barrier.wait()
 
@@ -400,21 +575,48 @@ class ThreadComm:
 
 
 class SlabSimulation:
-    """main.py:50-60 over `world` slabs.  Every rank passes its own particles (see slab_of) and their
-    numbers in the whole run; `engine` defaults to HipSlabEngine on cuda:`device_index`."""
+    """main.py:50-60 over `world` slabs.  Every rank passes its own particles and their numbers in the whole run; `engine`
+    defaults to HipSlabEngine on cuda:`device_index`.
+
+    Which particles are a rank's own: those of its slab (slab_of) by default.  With `cuts` (balanced_cuts / equal_cuts:
+    the first plane of every rank's window, and G) they are those whose cell lies in the rank's window (owner_by_cuts),
+    and the mesh planes a window's deposit writes travel to the slabs that transform them, the potential back: the
+    particle work is then divided by particle count, not by volume, whatever the slabs hold.  That needs an engine with
+    room for windows (HipSlabEngine(window_planes=...); window_planes here makes one).  rebalance() cuts the windows anew
+    from where the particles are now; balance_every = k > 0 does so every k steps when the fullest rank holds more than
+    balance_threshold times the mean."""
 
     def __init__(self, grid_size, box_size, positions, velocities, masses, ids, *, group=None, device_index=0, engine=None,
-                 capacity=None, always_collective=False, transpose_chunks=None, comm=None):
+                 capacity=None, always_collective=False, transpose_chunks=None, comm=None, cuts=None, window_planes=None,
+                 balance_every=0, balance_threshold=1.2, generate=None):
         self.comm = comm if comm is not None else _Comm(group, always_collective)
         self.G, self.L = int(grid_size), float(box_size)
         world, rank = self.comm.world, self.comm.rank
         if self.G % world:
             raise ValueError("grid_size must be a multiple of the number of ranks")
         self.Gs = self.G // world
-        n = len(positions)
+        n = len(positions) if positions is not None else 0
         cap = int(capacity) if capacity else int(1.5 * n) + 4096
-        self.engine = engine if engine is not None else HipSlabEngine(self.G, self.L, rank * self.Gs, self.Gs, cap, device_index)
-        self.engine.set_particles(positions, velocities, masses, ids)
+        if engine is None and (cuts is not None or window_planes is not None) and world > 1:
+            window_planes = int(window_planes) if window_planes is not None else min(self.G - 3, max(self.Gs, self.G // 2))
+        self.engine = engine if engine is not None else HipSlabEngine(self.G, self.L, rank * self.Gs, self.Gs, cap, device_index,
+                                                                      window_planes=window_planes if world > 1 else None)
+        self.windowed = bool(getattr(self.engine, "windowed", False))
+        self.cuts = equal_cuts(self.G, world)
+        if cuts is not None and list(cuts) != self.cuts:
+            if not self.windowed:
+                raise ValueError("windows other than the slabs need an engine with room for them (window_planes)")
+            self.cuts = [int(x) for x in cuts]
+            self.engine.set_window(self.cuts)
+        if generate is not None:
+            # generate = (kind, n, seed, params): the rank's share of a synthetic set, drawn where it lives
+            kind, n_all, seed, params = generate
+            self.engine.generate(kind, n_all, seed, **(params or {}))
+        else:
+            self.engine.set_particles(positions, velocities, masses, ids)
+        self._plan()
+        self.balance_every, self.balance_threshold = int(balance_every), float(balance_threshold)
+        self.steps_done, self.rebalanced = 0, 0
         self.next, self.prev = (rank + 1) % world, (rank - 1) % world
         # groups of planes the two transposes are cut into (see the module text).  By default two where a transpose is long
         # against the launches it costs (a 1024^3 mesh and larger), one -- the plain all-to-all -- below that.
@@ -428,6 +630,13 @@ class SlabSimulation:
         self.profile = False
         self._marks = []
         self._on_gpu = isinstance(self.engine, HipSlabEngine)
+
+    def _plan(self):
+        """Who sends which planes to whom, from the cuts (every rank computes the plans of all ranks: the sizes it will
+        receive follow from them, nothing about them is exchanged)."""
+        world = self.comm.world
+        self._dep = [plane_segments(self.cuts, self.G, r, 0, 1) for r in range(world)]      # what a deposit writes
+        self._pot = [plane_segments(self.cuts, self.G, r, 1, 2) for r in range(world)]      # what a gather reads
 
     PHASES = ("deposit", "density_halo", "fft_zy", "transpose", "solve_x", "transpose_back", "ifft_yz", "potential_halo",
               "gather_kick_drift", "migration")
@@ -464,7 +673,10 @@ class SlabSimulation:
     def step(self, dt, nsteps=1):
         try:
             for _ in range(nsteps):
+                if self.windowed and self.balance_every > 0 and self.steps_done > 0 and self.steps_done % self.balance_every == 0:
+                    self.rebalance(only_above=self.balance_threshold)
                 self._step(dt)
+                self.steps_done += 1
         except BaseException:
             # slabs that are threads of one process: the others must not wait at a barrier this one will never reach
             abort = getattr(self.comm, "abort", None)
@@ -480,9 +692,12 @@ class SlabSimulation:
         # deposit; the plane beyond the slab belongs to the next rank (functions.py:56: i1 = (i + 1) % G)
         e.deposit()
         mark("deposit")
-        ghost = e.ghost_out()
-        from_prev, _ = comm.shift(ghost, ghost.new_empty(0), ghost.numel(), 0)
-        e.ghost_in(from_prev)
+        if self.windowed:
+            self._window_planes_to_slabs()
+        else:
+            ghost = e.ghost_out()
+            from_prev, _ = comm.shift(ghost, ghost.new_empty(0), ghost.numel(), 0)
+            e.ghost_in(from_prev)
         mark("density_halo")
         # compute_potential (functions.py:73-89)
         exchange = world > 1 or (comm.always and comm.on)
@@ -527,17 +742,26 @@ class SlabSimulation:
             e.unpack(blocks)
             e.fft2(+1)
             mark("ifft_yz")
-        # potential planes beside the slab: one below (from the previous rank), two above (from the next rank)
-        to_next = e.planes_out(1, Gs, 1)            # my last owned plane
-        to_prev = e.planes_out(1, 1, 2)             # my first two owned planes
-        below, above = comm.shift(to_next, to_prev, plane, 2 * plane)
-        e.planes_in(1, 0, below.reshape(1, G, G))
-        e.planes_in(1, Gs + 1, above.reshape(2, G, G))
+        if self.windowed:
+            self._slab_potential_to_windows()
+        else:
+            # potential planes beside the slab: one below (from the previous rank), two above (from the next rank)
+            to_next = e.planes_out(1, Gs, 1)            # my last owned plane
+            to_prev = e.planes_out(1, 1, 2)             # my first two owned planes
+            below, above = comm.shift(to_next, to_prev, plane, 2 * plane)
+            e.planes_in(1, 0, below.reshape(1, G, G))
+            e.planes_in(1, Gs + 1, above.reshape(2, G, G))
         mark("potential_halo")
         # gradient, gather, kick, drift (main.py:54-60); then the particles that changed slab: how many go where is
         # exchanged between the ranks before anyone reads it, so the host waits for the device once per step
         e.gather_kick_drift(dt)
         mark("gather_kick_drift")
+        self._migrate()
+        mark("migration")
+
+    def _migrate(self):
+        """The particles in the engine's outbox (leavers of a drift, or of a change of windows) to the ranks that own them now."""
+        e, world, comm = self.engine, self.comm.world, self.comm
         mine = e.outbox_counts()                    # world + 1 entries, where the engine's data lives
         # every rank learns of every rank's trouble word (it travels beside the count), so that all of them raise in the
         # same step instead of one raising and the others waiting for it in the next exchange
@@ -554,7 +778,91 @@ class SlabSimulation:
         offs = np.concatenate(([0], np.cumsum(counts))) * 8
         got = comm.all_to_all([flat[offs[p]:offs[p + 1]] for p in range(world)], [8 * k for k in incoming])
         e.inbox(torch.cat(got).reshape(-1, 8))
-        mark("migration")
+
+    def _window_planes_to_slabs(self):
+        """What the deposit wrote -- the planes of this rank's window and the one above -- to the ranks whose slabs hold those
+        planes.  A slab's plane gets the plane of the window that contains it (copied), then the plane above the window
+        before that one (added, functions.py:56): one fixed order."""
+        e, world, comm, rank = self.engine, self.comm.world, self.comm, self.comm.rank
+        elems = e.deposit_plane_elems
+        out = [[] for _ in range(world)]
+        for t0, count, owner, first in self._dep[rank]:
+            if owner != rank:
+                out[owner].append(e.deposit_planes_out(t0, count))
+        dev = getattr(e, "device", torch.device("cpu"))
+        chunks = [torch.cat(x) if x else torch.empty(0, dtype=torch.float32, device=dev) for x in out]
+        sizes = [sum(c for _, c, o, _ in self._dep[src] if o == rank) * elems if src != rank else 0 for src in range(world)]
+        got = comm.all_to_all(chunks, sizes) if world > 1 else [chunks[0]]
+        for ghosts in (False, True):
+            for src in range(world):
+                wn, at = self.cuts[src + 1] - self.cuts[src], 0
+                for t0, count, owner, first in self._dep[src]:
+                    if owner != rank:
+                        continue
+                    is_ghost = t0 >= wn
+                    if is_ghost == ghosts:
+                        if src == rank:
+                            e.own_deposit_planes(t0, first, count, add=ghosts)
+                        else:
+                            e.mesh_planes_in(first, got[src][at:at + count * elems], add=ghosts)
+                    if src != rank:
+                        at += count * elems
+
+    def _slab_potential_to_windows(self):
+        """The potential of every window's planes, the one below and the two above, from the ranks whose slabs hold them."""
+        e, world, comm, rank, G = self.engine, self.comm.world, self.comm, self.comm.rank, self.G
+        plane = G * G
+        out = [[] for _ in range(world)]
+        for dest in range(world):
+            if dest != rank:
+                out[dest] = [e.mesh_potential_out(first, count) for _, count, owner, first in self._pot[dest] if owner == rank]
+        dev = getattr(e, "device", torch.device("cpu"))
+        chunks = [torch.cat(x) if x else torch.empty(0, dtype=torch.float32, device=dev) for x in out]
+        sizes = [sum(c for _, c, o, _ in self._pot[rank] if o == src) * plane if src != rank else 0 for src in range(world)]
+        got = comm.all_to_all(chunks, sizes) if world > 1 else [chunks[0]]
+        at = [0] * world
+        for t0, count, owner, first in self._pot[rank]:
+            if owner == rank:
+                e.own_potential_planes(first, t0, count)
+            else:
+                e.planes_in(1, t0, got[owner][at[owner]:at[owner] + count * plane].reshape(count, G, G))
+                at[owner] += count * plane
+
+    def loads(self):
+        """Particles every rank holds now (a list of world numbers, the same on every rank)."""
+        world = self.comm.world
+        n = torch.full((world,), int(self.engine.n), dtype=torch.int64, device=self.engine.device if self._on_gpu else "cpu")
+        return [int(x) for x in self.comm.exchange_counts(n).cpu().tolist()]
+
+    def plane_weight(self, n_total):
+        """balanced_cuts' plane_weight for this mesh and a set of n_total particles: half the mean number of particles per plane"""
+        return 0.5 * float(n_total) / self.G
+
+    def rebalance(self, only_above=None):
+        """Cuts the windows anew so that every rank holds (nearly) the same number of particles, from the particles per
+        mesh plane summed over the ranks; particles change hands accordingly.  Between steps only.  only_above = x: nothing
+        is done unless the fullest rank holds more than x times the mean.  Returns whether the windows changed."""
+        if not self.windowed:
+            raise ValueError("this simulation's particles are those of its slabs: make it with cuts or window_planes")
+        e, world = self.engine, self.comm.world
+        if only_above is not None:
+            # (the measure is the one the windows are cut by: particles, and plane_weight per plane of the window)
+            loads = self.loads()
+            w = self.plane_weight(sum(loads))
+            cost = [n + w * (b - a) for n, a, b in zip(loads, self.cuts, self.cuts[1:])]
+            if max(cost) <= only_above * (sum(cost) / world):
+                return False
+        counts = self.comm.all_reduce_sum(e.plane_counts()).cpu().numpy()
+        cuts = balanced_cuts(counts, world, e.window_planes, self.plane_weight(counts.sum()))
+        if cuts == self.cuts:
+            return False
+        e.set_window(cuts)
+        self.cuts = cuts
+        self._plan()
+        e.rekey()
+        self._migrate()
+        self.rebalanced += 1
+        return True
 
     def particles(self):
         """(ids, positions, velocities) of the particles this rank owns now."""

@@ -6,18 +6,27 @@ import scipy.fft as sfft
 import torch
 
 from oracle import pm_oracle as O
-from pm.distributed import slab_of
+from pm.distributed import equal_cuts, owner_by_cuts, plane_of
 
 
 class OracleSlabEngine:
-    def __init__(self, grid_size, box_size, plane0, nplanes):
+    """windowed = True: the particles are those of a window of planes set by set_window (the slab to begin with), the
+    deposit writes the window's planes into a buffer of its own, and the slab's planes (self.density, what fft2 reads;
+    self.mesh_pot, what it writes) are put together by the caller's exchanges -- as HipSlabEngine(window_planes=...) does."""
+
+    def __init__(self, grid_size, box_size, plane0, nplanes, windowed=False, window_planes=None):
         self.G, self.L, self.i0, self.Gs = int(grid_size), int(box_size), int(plane0), int(nplanes)
         self.world = self.G // self.Gs
         self.rank = self.i0 // self.Gs
         self.pitch = self.G // 2 + 1
         G, Gs = self.G, self.Gs
+        self.windowed = bool(windowed)
+        self.window_planes = int(window_planes) if window_planes else (G - 3 if windowed else Gs)
+        self.cuts = equal_cuts(G, self.world)
+        self.w0, self.wn = self.i0, Gs
         self.density = np.zeros((Gs + 1, G, G), np.float32)
         self.potential = np.zeros((Gs + 3, G, G), np.float32)
+        self.mesh_pot = np.zeros((Gs, G, G), np.float32)
         self.spec = np.zeros((Gs, G, self.pitch), np.complex64)
         self._t = torch.zeros((G * Gs * self.pitch, 2), dtype=torch.float32)
         self._out = (np.zeros(0, np.uint32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
@@ -25,12 +34,52 @@ class OracleSlabEngine:
     def close(self):
         pass
 
+    def owner(self, pos):
+        return owner_by_cuts(pos, self.G, self.L, self.cuts)
+
     def set_particles(self, pos, vel, mass, ids):
         self.pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
         self.vel = np.ascontiguousarray(vel, np.float32).reshape(-1, 3)
         self.mass = np.ascontiguousarray(mass, np.float32)
         self.ids = np.ascontiguousarray(ids, np.uint32)
-        assert np.all(slab_of(self.pos, self.G, self.L, self.world) == self.rank)
+        assert np.all(self.owner(self.pos) == self.rank)
+
+    # ---- windows -------------------------------------------------------------------------------------------
+    def set_window(self, cuts):
+        assert self.windowed and cuts[0] == 0 and cuts[-1] == self.G and len(cuts) == self.world + 1
+        self.cuts = [int(x) for x in cuts]
+        self.w0, self.wn = self.cuts[self.rank], self.cuts[self.rank + 1] - self.cuts[self.rank]
+        assert 1 <= self.wn <= self.window_planes
+        self.potential = np.zeros((self.wn + 3, self.G, self.G), np.float32)
+
+    def rekey(self):
+        self._leave(self.pos, self.vel)
+
+    def plane_counts(self):
+        return torch.from_numpy(np.bincount(plane_of(self.pos, self.G, self.L), minlength=self.G).astype(np.int64))
+
+    @property
+    def deposit_plane_elems(self):
+        return self.G * self.G
+
+    def deposit_planes_out(self, first, count):
+        return torch.from_numpy(self.wdens[first:first + count].copy()).reshape(-1)
+
+    def mesh_planes_in(self, first, planes, add):
+        a = planes.numpy().reshape(-1, self.G, self.G)
+        if add:
+            self.density[first:first + len(a)] += a
+        else:
+            self.density[first:first + len(a)] = a
+
+    def own_deposit_planes(self, first, mesh_first, count, add):
+        self.mesh_planes_in(mesh_first, torch.from_numpy(self.wdens[first:first + count].copy()), add)
+
+    def mesh_potential_out(self, first, count):
+        return torch.from_numpy(self.mesh_pot[first:first + count].copy()).reshape(-1)
+
+    def own_potential_planes(self, mesh_first, first, count):
+        self.potential[first:first + count] = self.mesh_pot[mesh_first:mesh_first + count]
 
     @property
     def n(self):
@@ -50,9 +99,13 @@ class OracleSlabEngine:
             self.density[G] = b[0]
             return
         full = O.CIC(self.pos, G, self.L, self.mass) if self.n else zero
-        planes = (self.i0 + np.arange(Gs + 1)) % G
-        self.density = full[planes].copy()
-        # nothing of a slab's particles lands outside its planes and the one above
+        planes = (self.w0 + np.arange(self.wn + 1)) % G
+        if self.windowed:
+            self.wdens = full[planes].copy()                # the caller's exchanges put self.density together from these
+            self.density[:] = np.nan                        # (every plane of the slab must be written by them)
+        else:
+            self.density = full[planes].copy()
+        # nothing of a rank's particles lands outside the planes of its window and the one above
         rest = np.ones(G, bool)
         rest[planes] = False
         assert not full[rest].any()
@@ -81,7 +134,14 @@ class OracleSlabEngine:
         if direction < 0:
             self.spec = sfft.rfft2(self.density[:self.Gs], axes=(1, 2)).astype(np.complex64)
         else:
-            self.potential[1:self.Gs + 1] = sfft.irfft2(self.spec, s=(self.G, self.G), axes=(1, 2)).astype(np.float32)
+            self._potential_planes(0, sfft.irfft2(self.spec, s=(self.G, self.G), axes=(1, 2)).astype(np.float32))
+
+    def _potential_planes(self, first, planes):
+        """planes first ... of the slab's potential"""
+        if self.windowed:
+            self.mesh_pot[first:first + len(planes)] = planes
+        else:
+            self.potential[1 + first:1 + first + len(planes)] = planes
 
     def pack(self):
         Gs, w = self.Gs, self.world
@@ -115,7 +175,7 @@ class OracleSlabEngine:
         Gs, w = self.Gs, self.world
         b = blocks.numpy().reshape(-1).view(np.complex64).reshape(w, Gs, Gs, self.pitch)
         spec = np.concatenate([b[p, first:first + count] for p in range(w)], axis=1)                # (count, G, pitch)
-        self.potential[1 + first:1 + first + count] = sfft.irfft2(spec, s=(self.G, self.G), axes=(1, 2)).astype(np.float32)
+        self._potential_planes(first, sfft.irfft2(spec, s=(self.G, self.G), axes=(1, 2)).astype(np.float32))
 
     def solve_x(self, spectrum_t):
         G, Gs = self.G, self.Gs
@@ -133,16 +193,22 @@ class OracleSlabEngine:
         a[...] = sfft.ifft(pk, axis=0).astype(np.complex64)
 
     def gather_kick_drift(self, dt):
-        G, Gs = self.G, self.Gs
-        full = np.zeros((G, G, G), np.float32)
-        for l in range(Gs + 3):
-            full[(self.i0 - 1 + l) % G] = self.potential[l]
+        G = self.G
+        full = np.full((G, G, G), np.nan, np.float32)       # (planes the gather must not touch)
+        for l in range(self.wn + 3):
+            full[(self.w0 - 1 + l) % G] = self.potential[l]
         if self.n:
-            forces = O.force_CIC(O.gradient(full), self.pos, G, self.L)
+            grad = O.gradient(full)
+            forces = O.force_CIC(grad, self.pos, G, self.L)
+            assert np.isfinite(forces).all()
             x, v = O.kick_drift(self.pos, self.vel, forces, dt, self.L)
         else:
             x, v = self.pos, self.vel
-        dest = slab_of(x, G, self.L, self.world) if self.n else np.zeros(0, np.int64)
+        self._leave(x, v)
+
+    def _leave(self, x, v):
+        """x, v: the live particles' positions and velocities; those whose cell lies in another rank's window go to the outbox."""
+        dest = self.owner(x) if self.n else np.zeros(0, np.int64)
         out = dest != self.rank
         order = np.lexsort((self.ids[out], dest[out]))
         self._out = (self.ids[out][order], x[out][order], v[out][order], self.mass[out][order])

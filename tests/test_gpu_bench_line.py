@@ -38,8 +38,36 @@ def test_single_gpu_line():
     assert "from_order_before" in d["last_binning"]
 
 
-def test_one_slab_line():
-    d = run_bench("--gpus", "1", "--parallelism", "slab", "--n", "1048576", "--grid", "128", "--workload", "uniform", "--steps", "3", "--warmup", "2")
-    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["collective_world_size"] == 1
+def check_slab_line(d, n, steps, world):
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["steps"] == steps
+    c = d["config"]
+    assert c["collective_world_size"] == world and (c["backend"] in ("gloo", "nccl") if world > 1 else c["backend"] is None)
+    assert sum(c["particles_per_rank_at_start"]) == n and sum(c["particles_per_rank_at_end"]) == n
     assert set(d["phases_ms"]) >= {"deposit", "transpose", "solve_x", "transpose_back", "gather_kick_drift", "migration"}
-    assert abs(d["value"] - 1048576 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+    assert abs(d["value"] - n * steps / (d["ms_per_step"] * steps * 1e-3)) <= 1e-6 * d["value"]
+    assert len(d["kernel_ms_per_rank"]) == world and len(d["local_work_ms_per_rank"]) == world
+    assert all(k["gather"] > 0 and k["deposit_rows"] > 0 and k["col_x_green"] > 0 for k in d["kernel_ms_per_rank"])
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and 0 <= r["rank"] < world
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert d["step_roofline"]["peak"] == 8000.0 * world
+
+
+def test_one_slab_line():
+    d = run_bench("--gpus", "1", "--parallelism", "slab", "--n", "1048576", "--grid", "128", "--workload", "uniform", "--steps", "3", "--warmup", "2",
+                  "--cpu-baseline", "skip")
+    check_slab_line(d, 1048576, 3, 1)
+    assert d["config"]["particle_ownership"] == "by slab"
+
+
+def test_two_rank_line_with_windows_and_device_drawn_particles():
+    """Two ranks on the one GPU of the test box, exchanging through the host (gloo): a rehearsal of the line a multi-GPU run
+    prints -- the clustered set is held by windows of equal particle count, and every rank draws its share on the device."""
+    d = run_bench("--gpus", "2", "--backend", "gloo", "--n", "2097152", "--grid", "128", "--workload", "two_galaxy", "--steps", "3", "--warmup", "2",
+                  "--no-uniform", "--device-ic", "--balance", "on", "--balance-every", "2")
+    check_slab_line(d, 2097152, 3, 2)
+    c = d["config"]
+    assert c["particle_ownership"] == "windows of equal particle count" and c["backend"] == "gloo"
+    assert c["window_cuts_at_start"][0] == 0 and c["window_cuts_at_start"][-1] == 128
+    assert max(c["particles_per_rank_at_start"]) <= 1.2 * 2097152 / 2
+    assert "drawn on the device" in d["data"]

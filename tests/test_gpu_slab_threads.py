@@ -14,22 +14,27 @@ pytestmark = pytest.mark.gpu
 _create = threading.Lock()
 
 
-def run_threads(world, build, steps, dt, chunks=None):
-    """build(rank) -> (G, L, pos, vel, mass, ids, capacity); returns per rank [(ids, pos, vel) after each step]."""
+def run_threads(world, build, steps, dt, chunks=None, keep="all", info=None, **sim_args):
+    """build(rank) -> (G, L, pos, vel, mass, ids, capacity); returns per rank [(ids, pos, vel) after each step] (keep =
+    "last": after the last step only).  sim_args go to SlabSimulation; info(rank, sim) -> anything is called at the end and
+    its results are returned as a second list."""
     from pm.distributed import SlabSimulation, ThreadComm
     comms = ThreadComm.make(world)
-    results, errors = [None] * world, []
+    results, errors, infos = [None] * world, [], [None] * world
 
     def run(r):
         try:
             G, L, pos, vel, mass, ids, cap = build(r)
             with _create:                                   # contexts are made one at a time
-                sim = SlabSimulation(G, L, pos, vel, mass, ids, device_index=0, capacity=cap, comm=comms[r], transpose_chunks=chunks)
+                sim = SlabSimulation(G, L, pos, vel, mass, ids, device_index=0, capacity=cap, comm=comms[r], transpose_chunks=chunks, **sim_args)
             del pos, vel, mass, ids
             out = []
-            for _ in range(steps):
+            for k in range(steps):
                 sim.step(dt)
-                out.append(sim.particles())
+                if keep == "all" or k == steps - 1:
+                    out.append(sim.particles())
+            if info is not None:
+                infos[r] = info(r, sim)
             sim.synchronize()
             sim.close()
             results[r] = out
@@ -43,7 +48,7 @@ def run_threads(world, build, steps, dt, chunks=None):
     for t in threads:
         t.join(600)
     assert not errors, errors
-    return results
+    return results if info is None else (results, infos)
 
 
 @pytest.mark.parametrize("case,world,chunks", [("g128", 4, None), ("g512", 8, 2)])
@@ -128,3 +133,99 @@ def test_mesh_of_the_eight_gpu_configuration():
     if free < 235e9:
         pytest.skip(f"needs about 200 GB of device memory for the eight slabs, {free / 1e9:.0f} GB are free")
     lattice_run(2048, 8, 128, 16, 2)
+
+
+def collect(results, n):
+    """(ids seen once each, positions, velocities) in the order of the particles' numbers, from every rank's last record."""
+    x, v, seen = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.zeros(n, bool)
+    for out in results:
+        i, xi, vi = out[-1]
+        assert not seen[i].any()
+        seen[i] = True
+        x[i], v[i] = xi, vi
+    assert seen.all()
+    return x, v
+
+
+@pytest.mark.parametrize("mode", ["cut at the start", "cut anew during the run"])
+def test_windows_of_equal_particle_count_on_a_clustered_set(mode):
+    """The two-galaxy collision on 512^3 in eight slabs, the particles held by windows of equal particle count instead of
+    by slab (the fullest of the eight slabs holds half of this set): the planes a window's deposit writes travel to the
+    slabs that transform them as z-transformed planes, the potential comes back, leavers go to the rank whose window
+    holds their new cell.  Against the one-context run: 1e-5 L and 1e-5 max|v| after three steps."""
+    import bench
+    import pm
+    from pm.distributed import balanced_cuts, equal_cuts, owner_by_cuts, plane_of, slab_of
+    n, G, L, dt, world, K = 1 << 21, 512, 10000, 0.005, 8, 3
+    pos, vel, mass = bench.make_workload("two_galaxy", n, L, 1052)
+    ids = np.arange(n, dtype=np.uint32)
+    by_slab = np.bincount(slab_of(pos, G, L, world), minlength=world)
+    assert by_slab.max() > 0.4 * n                          # what the windows are for
+    if mode == "cut at the start":
+        cuts = balanced_cuts(np.bincount(plane_of(pos, G, L), minlength=G), world, G // 2)
+        owner = owner_by_cuts(pos, G, L, cuts)
+        assert np.bincount(owner, minlength=world).max() < 1.25 * n / world
+        args = dict(cuts=cuts, window_planes=G // 2)
+    else:
+        cuts, owner = equal_cuts(G, world), slab_of(pos, G, L, world)
+        args = dict(window_planes=G // 2, balance_every=1, balance_threshold=1.2)
+
+    def build(r):
+        mine = owner == r
+        return G, L, pos[mine], vel[mine], mass[mine], ids[mine], int(max(mine.sum(), n // world) * 1.5) + 4096
+
+    def info(r, sim):
+        i, x, _ = sim.particles()
+        assert np.all(owner_by_cuts(x, G, L, sim.cuts) == r)        # everybody is where its cell's window is
+        return sim.loads(), sim.cuts, sim.rebalanced
+
+    res, infos = run_threads(world, build, K, dt, keep="last", info=info, **args)
+    loads, final_cuts, recuts = infos[0]
+    assert sum(loads) == n
+    if mode == "cut at the start":
+        assert max(loads) < 1.25 * n / world, loads
+    else:
+        # cut anew by particles + half a mean plane's particles per plane of the window (SlabSimulation.plane_weight)
+        assert recuts >= 1 and final_cuts != equal_cuts(G, world)
+        cost = [k + 0.5 * n / G * (b - a) for k, a, b in zip(loads, final_cuts, final_cuts[1:])]
+        assert max(cost) < 1.25 * sum(cost) / world, (loads, final_cuts)
+    x, v = collect(res, n)
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+        sim.step(dt, K)
+        xr, vr = sim.positions(), sim.velocities()
+    dx = np.abs(x.astype(np.float64) - xr)
+    assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+    assert np.abs(v - vr).max() <= 1e-5 * np.abs(vr).max()
+
+
+def test_synthetic_sets_drawn_slab_by_slab():
+    """pm_generate on slab contexts: every slab draws the whole set and keeps the particles of its window, in the order
+    of their numbers -- together they are the set a one-context pm_generate draws, bit for bit; and the plane counts every
+    rank computes for itself are the set's."""
+    import pm
+    from pm.distributed import HipSlabEngine, balanced_cuts, plane_of
+    n, G, L, world = 300_000, 128, 10000, 4
+    for kind in ("two_galaxy", "uniform"):
+        with pm.Simulation(G, L, capacity=n) as sim:
+            sim.generate(kind, n, seed=7)
+            xr, vr = sim.positions(), sim.velocities()
+        counts = np.bincount(plane_of(xr, G, L), minlength=G)
+        seen = np.zeros(n, bool)
+        cuts = None
+        for r in range(world):
+            eng = HipSlabEngine(G, L, r * (G // world), G // world, n, 0, window_planes=G - 3)
+            try:
+                got = eng.generate_plane_counts(kind, n, seed=7)
+                assert np.array_equal(got, counts)
+                cuts = balanced_cuts(got, world, G - 3)
+                eng.set_window(cuts)
+                eng.generate(kind, n, seed=7)
+                i, x, v = eng.particles()
+            finally:
+                eng.close()
+            assert np.all(np.diff(i.astype(np.int64)) > 0) and not seen[i].any()
+            seen[i] = True
+            assert np.array_equal(x, xr[i]) and np.array_equal(v, vr[i])
+            w = plane_of(x, G, L)
+            assert np.all((w >= cuts[r]) & (w < cuts[r + 1]))
+        assert seen.all()
