@@ -200,11 +200,13 @@ static int create_impl(pm_ctx *c)
     TRY(dalloc(c, &c->counters, 128));
     HIP_TRY(c, hipMemsetAsync(c->counters, 0, 128 * sizeof(uint32_t), c->stream));
     TRY(dalloc(c, &c->row_unit, planes * G + 1));
+    if (!c->slab && c->fft_custom) TRY(dalloc(c, &c->row_live, plane / 64 + 2));
     TRY(dalloc(c, &c->unit_src, pm_max_units(cap)));
     TRY(dalloc(c, &c->unit_rows, pm_max_units(cap) * 4 * (size_t)G));
     TRY(dalloc(c, &c->light_rows, pm_heavy_row_entries(G, cap) * (size_t)G));
     // a slab context keeps one more density plane and three more potential planes than it owns, and no gradient meshes
-    TRY(dalloc(c, &c->density, (planes + 1) * plane));
+    // (a context with room for windows always deposits z-transformed planes: no density mesh)
+    if (!(c->slab && c->wmax != c->slabn)) TRY(dalloc(c, &c->density, (planes + 1) * plane));
     TRY(dalloc(c, &c->potential, (planes + 3) * plane));
     if (!c->slab)
         for (int d = 0; d < 3; ++d) TRY(dalloc(c, &c->grad[d], M));
@@ -310,7 +312,7 @@ void pm_destroy(pm_ctx *c)
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac); hipFree(c->elog);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
-    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src);
+    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src); hipFree(c->row_live);
     if (c->slab && c->wmax != c->slabn) { hipFree(c->mesh_spec); hipFree(c->mesh_pot); }      // (else they alias spectrum / potential)
     hipFree(c->cuts);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
@@ -535,7 +537,7 @@ static int potential_impl(pm_ctx *c, bool have_z)
         const int group = c->g.G <= 512 ? PM_COL_GROUP : tiles;
         for (int t0 = 0; t0 < tiles; t0 += group) {
             const int nt = t0 + group <= tiles ? group : tiles - t0;
-            HIP_TRY(c, pm_launch_col_fft_tiles(c, -1, t0, nt));
+            HIP_TRY(c, pm_launch_col_fft_tiles(c, -1, t0, nt, have_z && c->rows_marked));
             HIP_TRY(c, pm_launch_col_fft_tiles(c, 0, t0, nt));
             HIP_TRY(c, pm_launch_col_fft_tiles(c, 1, t0, nt));
         }
@@ -547,7 +549,7 @@ static int potential_impl(pm_ctx *c, bool have_z)
         if (c->fft_custom) {
             if (!have_z) HIP_TRY(c, pm_launch_row_fft(c, true));
             kernel_timer k(c, PM_KERNEL_COL_Y_FWD);
-            HIP_TRY(c, pm_launch_col_fft(c, -1));
+            HIP_TRY(c, pm_launch_col_fft(c, -1, have_z && c->rows_marked));
         } else {
             void *in[1] = {c->density}, *out[1] = {c->spectrum};
             FFT_TRY(c, rocfft_execute(c->fwd, in, out, c->info));

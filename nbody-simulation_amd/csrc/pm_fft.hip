@@ -56,6 +56,9 @@ struct col_pass {
     float2 *blocks;
     int gs_shift;           // log2 Gs
     int64_t block_stride;   // Gs * Gs * pitch
+    // forward pass along y of a whole mesh right after a deposit that marked its empty rows (k_plan_units): bit (outer * G +
+    // row) says whether the row was written; the others are zeros that are not read.  Null: every row is read.
+    const unsigned long long *row_live;
 };
 
 // Radix plan of the column transform: N = R1 * 8 * 8 (R1 = 2, 4, 8, 16, 32 at N = 128, 256, 512, 1024, 2048).  A column is
@@ -131,13 +134,20 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
     constexpr int EPT = plan::EPT;
     float2 v[EPT];
     // ---- stage 1 inputs from global: v[b * R1 + r] = row jl + TPC b + 64 r
+    // (rows jl + 64 m, m = 0 .. N / 64 - 1, of plane `outer`: bit jl of each of the plane's N / 64 words of row_live)
+    constexpr bool MARKED = BLK == 0 && !GREEN && DIR < 0 && TPC == 64 && NB1 == 1;
+    const unsigned long long *live = MARKED ? p.row_live : nullptr;
 #pragma unroll
     for (int b = 0; b < NB1; ++b)
 #pragma unroll
         for (int r = 0; r < R1; ++r) {
             int row = jl + TPC * b + 64 * r;
             if (BLK == 2) v[b * R1 + r] = valid ? in_blocks(row) : make_float2(0.0f, 0.0f);
-            else v[b * R1 + r] = valid ? in_spec(row) : make_float2(0.0f, 0.0f);
+            else if (MARKED && live != nullptr) {
+                // (the word is the same for all threads of the workgroup: a scalar load)
+                const unsigned long long w = live[(size_t)outer * (N / 64) + (b * R1 + r)];
+                v[b * R1 + r] = (valid && ((w >> jl) & 1ull)) ? in_spec(row) : make_float2(0.0f, 0.0f);
+            } else v[b * R1 + r] = valid ? in_spec(row) : make_float2(0.0f, 0.0f);
         }
 
     auto stage1_out = [&](auto dir) {
@@ -426,21 +436,23 @@ static void spectrum_strides(pm_ctx *c, col_pass &p, bool along_i)
 }
 
 // dir < 0: forward along j.  dir > 0: inverse along j.  dir == 0: forward along i, Green multiply, inverse along i.
-hipError_t pm_launch_col_fft(pm_ctx *c, int dir)
+hipError_t pm_launch_col_fft(pm_ctx *c, int dir, bool rows_marked)
 {
     const int G = c->g.G;
     col_pass p = pass_for(c, c->spectrum);
     spectrum_strides(c, p, dir == 0);
+    if (rows_marked && dir < 0) p.row_live = c->row_live;
     return launch_col_any(c, dir, p, G * p.tiles);
 }
 
 // The same on column tiles [tile0, tile0 + ntiles) only (a tile is 16 neighbouring columns c of all rows).
-hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles)
+hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles, bool rows_marked)
 {
     const int G = c->g.G;
     col_pass p = pass_for(c, c->spectrum);
     spectrum_strides(c, p, dir == 0);
     p.tile0 = tile0; p.ntiles = ntiles;
+    if (rows_marked && dir < 0) p.row_live = c->row_live;
     return launch_col_any(c, dir, p, G * ntiles);
 }
 

@@ -123,6 +123,8 @@ struct pm_ctx {
     size_t sort_tmp_bytes = 0;
     uint32_t *row_start = nullptr;      // G*G + 1 entries: first particle of every mesh row (i,j,:)
     uint32_t *row_unit = nullptr;       // per mesh row: first unit of a crowded row, or none
+    unsigned long long *row_live = nullptr;     // whole meshes: a bit per density row, set where the deposit has something to add (k_plan_units)
+    bool rows_marked = false;           // the last deposit left its empty rows unwritten and marked them in row_live instead
     uint32_t *unit_src = nullptr;       // per unit: the mesh row it is a part of
     uint2 *heavy_rows = nullptr;        // density rows with a crowded source: (row, has a partial sum in light_rows)
     uint32_t *counters = nullptr;       // units handed out, density rows listed: two sets of 64 words that take turns
@@ -262,7 +264,7 @@ bool pm_fft_custom_supported(int G);
 int pm_fft_spectrum_interleave(int G);       // log2 of the planes interleaved in a whole-mesh half spectrum (pm_geom::sb)
 int pm_fft_pitch(int G);
 hipError_t pm_fft_upload_twiddles(pm_ctx *c);
-hipError_t pm_launch_col_fft(pm_ctx *c, int dir);
+hipError_t pm_launch_col_fft(pm_ctx *c, int dir, bool rows_marked = false);
 // the same transforms on `planes` planes of a slab: z and y passes between real planes and spectrum planes, and the
 // x pass (forward, Green multiply, inverse) on the transposed spectrum (G, planes, Ghp) whose rows are y = y0 ...
 hipError_t pm_launch_row_fft_planes(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int planes);
@@ -283,7 +285,8 @@ hipError_t pm_launch_set_ids(pm_ctx *c, const uint32_t *ids);
 hipError_t pm_launch_export_slab(pm_ctx *c, uint32_t *ids, float *pos, float *vel);
 hipError_t pm_launch_outbox_counts(pm_ctx *c, int64_t *device_counts);
 hipError_t pm_launch_row_fft(pm_ctx *c, bool forward);
-hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles);
+// (rows_marked: the forward pass along y takes the rows that row_live marks empty as zeros, without reading them)
+hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles, bool rows_marked = false);
 int pm_fft_tiles(const pm_ctx *c);
 hipError_t pm_launch_gradient(pm_ctx *c);
 hipError_t pm_launch_gather(pm_ctx *c, double dt, bool integrate, bool store_forces, bool fused_gradient);

@@ -535,10 +535,12 @@ __device__ __forceinline__ void emit_row(double *acc, const float2 *tw, float *_
 }
 
 template <int NFFT>
-__device__ __forceinline__ void emit_empty_row(float *__restrict__ density, float2 *__restrict__ spectrum, uint32_t row, int G, int pitch, int sb)
+__device__ __forceinline__ void emit_empty_row(float *__restrict__ density, float2 *__restrict__ spectrum, uint32_t row, int G, int pitch, int sb,
+                                               bool rows_marked)
 {
     const int j = lane_id();
     if constexpr (NFFT != 0) {
+        if (rows_marked) return;                        // (k_plan_units has marked the row empty: nobody reads it)
         float2 *dst = spectrum + pm_spec_row(NFFT, sb, (int)(row / NFFT), (int)(row % NFFT)) * pitch;
         for (int c = j; c <= G / 2; c += 64) dst[c] = make_float2(0.0f, 0.0f);
     } else {
@@ -549,11 +551,25 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
 
 // Crowded source rows get their units: row_unit[row] = index of the row's first unit (NO_UNIT for the other rows),
 // unit_src[u] = the row unit u belongs to.  One counter update per wave.
+// row_live (may be null; whole meshes only, G a multiple of 64): a bit per DENSITY row, set where one of the four mesh rows
+// that feed it holds a particle.  Where it is written, the deposit writes nothing for the other rows and the transform
+// along y that follows takes them as zeros without reading them.
 __global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32_t *__restrict__ row_unit, uint32_t *__restrict__ unit_src,
-                             uint32_t *__restrict__ counters)
+                             uint32_t *__restrict__ counters, unsigned long long *__restrict__ row_live, uint32_t G)
 {
     const uint32_t row = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t len = row < R ? rs[row + 1] - rs[row] : 0u;
+    if (row_live != nullptr) {
+        bool live = len != 0u;
+        if (row < R && !live) {
+            const uint32_t i = row / G, j = row - i * G;
+            const uint32_t im = i == 0u ? G - 1u : i - 1u, jm = j == 0u ? G - 1u : j - 1u;
+            const uint32_t a = im * G + j, b = i * G + jm, c = im * G + jm;
+            live = rs[a + 1] != rs[a] || rs[b + 1] != rs[b] || rs[c + 1] != rs[c];
+        }
+        const unsigned long long m = __ballot(live);
+        if (lane_id() == 0 && row < R) row_live[row >> 6] = m;
+    }
     const uint32_t units = len > HEAVY_SRC ? (len + UNIT - 1) / UNIT : 0u;
     uint32_t before = units;                                    // inclusive scan over the wave
 #pragma unroll
@@ -583,7 +599,7 @@ __global__ void __launch_bounds__(BLOCK, TIGHT ? 8 : 1)
 k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
                const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, float *__restrict__ density,
                float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
-               uint2 *__restrict__ heavy_rows, uint32_t *__restrict__ counters, double *__restrict__ light_rows, pm_geom g)
+               uint2 *__restrict__ heavy_rows, uint32_t *__restrict__ counters, double *__restrict__ light_rows, pm_geom g, bool rows_marked)
 {
     extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then the NFFT twiddles
     TRACE_BEGIN
@@ -634,7 +650,7 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
     }
     if (!in_range) return;
     if (t.longest == 0 && !crowded) {
-        emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp, g.sb);
+        emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp, g.sb, rows_marked);
         TRACE_END(0, row, 0u)
         return;
     }
@@ -1174,7 +1190,12 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     uint32_t *counters = c->counters + 64 * c->counter_set, *next_counters = c->counters + 64 * (1 - c->counter_set);
     c->counter_set = 1 - c->counter_set;
     hipError_t e = hipSuccess;
-    k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, counters);
+    // (a whole mesh whose rows leave as half-spectrum rows for the pass along y of this library: the empty rows are marked
+    // instead of written)
+    // (grid sizes whose pass along y has a thread read rows jl, jl + 64, ...: one word of the marks per row read)
+    const bool mark_rows = (NFFT == 512 || NFFT == 1024) && !c->slab && c->row_live != nullptr;
+    c->rows_marked = mark_rows;
+    k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, counters, mark_rows ? c->row_live : nullptr, (uint32_t)G);
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
     const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);
@@ -1222,10 +1243,10 @@ static hipError_t deposit_dispatch(pm_ctx *c)
         // (no crowded rows lately -- the same word that decides where the units run: the instantiation for such sets)
         if (beside)
             k_deposit_rows<NFFT, false><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
-                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g);
+                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
         else
             k_deposit_rows<NFFT, true><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
-                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g);
+                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
     }
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
     k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,

@@ -229,3 +229,152 @@ def test_synthetic_sets_drawn_slab_by_slab():
             w = plane_of(x, G, L)
             assert np.all((w >= cuts[r]) & (w < cuts[r + 1]))
         assert seen.all()
+
+
+def test_disk_of_the_clustered_configuration_in_eight_windows():
+    """The clustered-disk configuration (N = 67,108,864 on 1024^3: crowded rows, deposit units) over eight ranks as threads
+    on the one GPU: every rank draws its share on the device and holds a window of equal load (the two middle slabs of
+    eight would hold nearly all of this set); one step with migration, and a second one, against the one-context run."""
+    import torch
+    import pm
+    from pm.distributed import balanced_cuts, generated_plane_counts, owner_by_cuts
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip(f"needs about 120 GB of device memory, {free / 1e9:.0f} GB are free")
+    n, G, L, dt, world, K = 67_108_864, 1024, 10000, 0.005, 8, 2
+    counts = generated_plane_counts(G, L, "disk", n, 42)
+    assert counts.sum() == n and counts.reshape(world, -1).sum(axis=1).max() > 0.45 * n
+    cuts = balanced_cuts(counts, world, G // 2, 0.5 * n / G)
+    loads = [int(counts[a:b].sum()) for a, b in zip(cuts, cuts[1:])]
+
+    def build(r):
+        return G, L, None, None, None, None, int(loads[r] * 1.25) + (1 << 20)
+
+    def info(r, sim):
+        i, x, _ = sim.particles()
+        assert np.all(owner_by_cuts(x, G, L, sim.cuts) == r)
+        return sim.loads()
+
+    res, infos = run_threads(world, build, K, dt, keep="last", info=info, cuts=cuts, window_planes=G // 2, generate=("disk", n, 42, None))
+    assert sum(infos[0]) == n
+    x, v = collect(res, n)
+    del res
+    with pm.Simulation(G, L, capacity=n, fused_gradient=True) as sim:
+        sim.generate("disk", n, seed=42)
+        sim.step(dt, K)
+        xr, vr = sim.positions(), sim.velocities()
+    dx = np.abs(x.astype(np.float64) - xr)
+    assert np.minimum(dx, L - dx).max() <= 1e-5 * L
+    # this set starts nearly at rest (sigma 10) and its velocities after two steps are the kicks of the dense disk: the two
+    # ways of summing a 1024^3 solve in float32 (planes added as z-spectra and transformed slab by slab; one context) agree to
+    # 1e-6 of max|phi|, which the difference quotient of the gradient carries into the kicks at 1e-5 of the largest (measured
+    # 1.02e-5; test_fused_step_1024 allows the rocFFT pipeline 5e-5 for the same reason)
+    assert np.abs(v - vr).max() <= 2e-5 * np.abs(vr).max()
+
+
+def gather_on_planes(phi, i_first, pos, vel, G, L, dt):
+    """force_CIC (functions.py:99-180) and main.py:58-60 for particles whose cells lie in mesh planes that `phi` covers:
+    phi[q] is plane i_first + q of the potential.  np.gradient's central difference along the first axis needs no plane
+    outside phi for the cells' two planes as long as those are not phi's first or last.  float64 weights, float32 sums
+    rounded at every add, the reference's corner order."""
+    from oracle import pm_oracle as O
+    c, d = O.cell_and_fraction_f64(pos, G, L)
+    grad = np.gradient(phi)
+    q = c[:, 0] - i_first
+    assert q.min() >= 1 and q.max() + 1 <= len(phi) - 2
+    c1 = (c + 1) % G
+    idx = np.stack((c, c1))
+    qi = np.stack((q, q + 1))
+    w = np.stack((1.0 - d, d))
+    f = np.zeros((len(c), 3), np.float32)
+    for di, dj, dk in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)):
+        wt = w[di, :, 0] * w[dj, :, 1] * w[dk, :, 2]
+        node = (qi[di], idx[dj, :, 1], idx[dk, :, 2])
+        for a in range(3):
+            f[:, a] = (f[:, a].astype(np.float64) + grad[a][node].astype(np.float64) * wt).astype(np.float32)
+    v1 = vel + f * np.float32(dt)
+    x1 = np.remainder(pos + v1 * np.float32(dt), np.float32(L))
+    return f, x1.astype(np.float32), v1.astype(np.float32)
+
+
+def test_gather_on_planes_is_the_oracle_gather():
+    """(the restatement above against the oracle's own force_CIC and kick_drift, where the whole mesh fits)"""
+    from oracle import pm_oracle as O
+    G, L, dt = 32, 10000, 0.005
+    rng = np.random.default_rng(2)
+    phi = rng.normal(0, 1e4, (G, G, G)).astype(np.float32)
+    pos = (rng.random((5000, 3)) * L).astype(np.float32)
+    pos[:, 0] = (rng.random(5000) * 10 + 7).astype(np.float32) * np.float32(L / G)       # cells in planes 7 .. 16
+    vel = rng.normal(0, 100, (5000, 3)).astype(np.float32)
+    f, x1, v1 = gather_on_planes(phi[5:20], 5, pos, vel, G, L, dt)
+    fo = O.force_CIC(O.gradient(phi), pos, G, L)
+    xo, vo = O.kick_drift(pos, vel, fo, dt, L)
+    assert np.array_equal(f, fo) and np.array_equal(x1, xo) and np.array_equal(v1, vo)
+
+
+def test_uniform_set_of_the_eight_gpu_configuration_on_its_mesh():
+    """The 8-GPU configuration's mesh (2048^3 in eight slabs of 256 planes) with the uniform random set, 2^26 of its 2^29
+    particles (what one MI355X holds beside the eight slabs' meshes), drawn on the device slab by slab.  No oracle runs a
+    2048^3 mesh, so the step is checked through what does not need one: every particle is owned once, by the slab that
+    holds its cell, before and after the step; the slabs' cell orders are the oracle's keys in order; the deposit
+    conserves the mass; and on a sample of one slab the kick and drift are the oracle's gather (force_CIC with
+    np.gradient, functions.py:99-180, main.py:54-60) of the potential planes that slab holds, bit for bit."""
+    import torch
+    from oracle import pm_oracle as O
+    from pm.distributed import slab_of
+    free, _ = torch.cuda.mem_get_info()
+    if free < 235e9:
+        pytest.skip(f"needs about 200 GB of device memory for the eight slabs, {free / 1e9:.0f} GB are free")
+    n, G, L, dt, world = 1 << 26, 2048, 10000, 0.005, 8
+    Gs = G // world
+    start, seen_mass = [None] * world, [0.0] * world
+
+    def build(r):
+        return G, L, None, None, None, None, n // world + n // 64 + 4096
+
+    # (run_threads is asked for zero steps: `info0` reads the particles as they were drawn, steps once itself and reads them again)
+    def info0(r, sim):
+        e = sim.engine
+        e.deposit()                                             # bins the particles: storage order = cell order
+        i, x, v = sim.particles()
+        assert np.all(slab_of(x, G, L, world) == r)
+        keys = O.cell_keys(x, G, L) - r * Gs * G * G
+        assert keys.min() >= 0 and keys.max() < Gs * G * G and np.all(np.diff(keys) >= 0)
+        same = np.diff(keys) == 0
+        assert np.all(np.diff(i.astype(np.int64))[same] > 0)    # ties keep the order of the particles' numbers
+        # the deposit's planes, transformed along z: their k = 0 terms are the planes' masses
+        dc = sum(float(e.deposit_planes_out(p0, min(32, Gs + 1 - p0)).view(-1, G, e.pitch, 2)[:, :, 0, 0].double().sum())
+                 for p0 in range(0, Gs + 1, 32))
+        seen_mass[r] = dc
+        start[r] = (i, x, v)
+        sim.step(dt)
+        i1, x1, v1 = sim.particles()
+        assert np.all(slab_of(x1, G, L, world) == r)
+        out = None
+        if r == 3:
+            # planes 0 .. 11 of this slab's potential buffer are mesh planes 3 Gs - 1 .. 3 Gs + 10
+            phi = e.planes_out(1, 0, 12).cpu().numpy()
+            cell_i = O.cell_index(x, G, L)[:, 0]
+            pick = np.flatnonzero((cell_i >= 3 * Gs + 1) & (cell_i <= 3 * Gs + 7))[::17][:40_000]
+            out = (phi, i[pick], x[pick], v[pick])
+        return i1, x1, v1, out
+
+    res, infos = run_threads(world, build, 0, dt, info=info0, generate=("uniform", n, 1052, None))
+    assert abs(sum(seen_mass) - n) <= 1e-6 * n
+    before = np.zeros(n, np.int32)
+    after = np.zeros(n, np.int32)
+    for r in range(world):
+        before[start[r][0]] += 1
+        after[infos[r][0]] += 1
+    assert np.all(before == 1) and np.all(after == 1)
+    moved = sum(int((slab_of(start[r][1], G, L, world) != r).sum()) for r in range(world))
+    assert moved == 0
+    # the sample of slab 3: where its particles are now (they may have changed slab), against the oracle's gather
+    phi, ids, x0, v0 = infos[3][3]
+    assert len(ids) > 10_000
+    f, xe, ve = gather_on_planes(phi, 3 * Gs - 1, x0, v0, G, L, dt)
+    x_all, v_all = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+    for r in range(world):
+        x_all[infos[r][0]], v_all[infos[r][0]] = infos[r][1], infos[r][2]
+    assert np.abs(f).max() > 0
+    assert np.array_equal(v_all[ids], ve) and np.array_equal(x_all[ids], xe)
