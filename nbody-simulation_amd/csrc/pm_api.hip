@@ -197,8 +197,8 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipMalloc(&c->sort_tmp, c->sort_tmp_bytes + 16));
     TRY(dalloc(c, &c->row_start, planes * G + 1));
     TRY(dalloc(c, &c->heavy_rows, pm_heavy_row_entries(G, cap)));
-    TRY(dalloc(c, &c->counters, 128));
-    HIP_TRY(c, hipMemsetAsync(c->counters, 0, 128 * sizeof(uint32_t), c->stream));
+    TRY(dalloc(c, &c->counters, 2 * 8256));        // two sets of the deposit's counters (pm_particles.hip: COUNTER_WORDS each, at most)
+    HIP_TRY(c, hipMemsetAsync(c->counters, 0, 2 * 8256 * sizeof(uint32_t), c->stream));
     TRY(dalloc(c, &c->row_unit, planes * G + 1));
     if (!c->slab && c->fft_custom) TRY(dalloc(c, &c->row_live, plane / 64 + 2));
     TRY(dalloc(c, &c->unit_src, pm_max_units(cap)));

@@ -232,7 +232,12 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
 // sources, in a fixed order.
 constexpr uint32_t PACKED_MAX = PM_PACKED_MAX, HEAVY_SRC = PM_HEAVY_SRC, UNIT = PM_UNIT, NO_UNIT = 0xffffffffu;
 constexpr int UNIT_BLOCK = 128;         // two waves, each with four LDS rows
-constexpr int COUNTER_UNITS = 0, COUNTER_ROWS = 32;     // counters[]: units handed out, density rows listed (own 128-byte lines)
+#ifndef PM_ROW_QUEUES
+#define PM_ROW_QUEUES 64
+#endif
+// counters[]: units handed out, density rows listed (own 128-byte lines), then the turn counters of the row kernel (a line each)
+constexpr int COUNTER_UNITS = 0, COUNTER_ROWS = 32, COUNTER_TICKETS = 64;
+constexpr uint32_t COUNTER_WORDS = 64 + PM_ROW_QUEUES * 32;         // words of one set of counters
 
 __device__ __forceinline__ void lds_add(double *p, double v)
 {
@@ -526,7 +531,9 @@ __device__ __forceinline__ void emit_row(double *acc, const float2 *tw, float *_
             v[r] = make_float2((float)acc[2 * n], (float)acc[2 * n + 1]);
         }
         float2 *buf = (float2 *)acc;                    // the row's LDS is free once every lane holds its part
+#ifndef PM_DEPOSIT_NOFFT
         pmfft::wave_fft<E, -1>(v, buf, tw, j);
+#endif
         pmfft::wave_r2c_split<E>(v, buf, tw, j, spectrum + pm_spec_row(NFFT, sb, (int)(row / NFFT), (int)(row % NFFT)) * pitch);
     } else {
         float *out = density + (size_t)row * G;
@@ -663,9 +670,13 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         if (t.longest == 0) return;
         entry = __builtin_amdgcn_readfirstlane(entry);
     }
+#ifdef PM_DEPOSIT_NOWALK
+    if (false) {} else if (p.total > 100000000u) {
+#else
     if (packed) {
         deposit_packed(F, key, p, first, G, acc);
     } else {
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) deposit_chunks(F, key, t.beg[q], t.end[q], t.key0[q], q & 1, q & 2, G, acc);
     }
@@ -677,6 +688,102 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
         emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp, g.sb);
     }
     TRACE_END(0, row, p.total | (crowded ? 0x80000000u : 0u))
+}
+
+// The same work by waves that stay: a workgroup loads the twiddles once and each of its waves takes density rows in
+// turn until none is left, so that a row costs what is done for it and not the start of a wave, a copy of the twiddle
+// table and a barrier as well (with one wave per row those are half of the kernel's time on a clustered set of 16.7 M
+// particles: 138 of 281 us with neither walk nor transform).  Rows are handed out one at a time, last rows first, by
+// ROW_QUEUES counters: workgroup b uses counter b % ROW_QUEUES and takes the rows r with r % ROW_QUEUES equal to that.
+// One row per turn, because consecutive rows are alike and a wave that takes several crowded ones in a row holds the
+// kernel up (eight rows per turn: 517 us; four: 394; two: 358; one: 293, against 327 for a wave per row); many
+// counters, because atomics on one address go at some 60 million a second, which the 32,768 turns per counter of eight
+// counters do not fit into (one row per turn on eight counters: 517 us).  A wave asks for its turn two rows ahead and for
+// the places of the next row's runs one row ahead, so that both are there when the row before is done.
+constexpr uint32_t ROW_TICKET_STRIDE = 32, ROW_QUEUES = PM_ROW_QUEUES;      // words between two counters (a 128-byte line each)
+
+template <int NFFT, bool TIGHT>
+__global__ void __launch_bounds__(BLOCK, TIGHT ? 8 : 1)
+k_deposit_rows_loop(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
+                    const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, float *__restrict__ density,
+                    float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
+                    uint2 *__restrict__ heavy_rows, uint32_t *__restrict__ counters, double *__restrict__ light_rows, pm_geom g, bool rows_marked,
+                    uint32_t *__restrict__ tickets)
+{
+    extern __shared__ double lds_rows[];                // BLOCK/64 rows of G doubles, then the NFFT twiddles
+    const int G = g.G;
+    const uint32_t R = (uint32_t)g.Gd * (uint32_t)G;
+    float2 *tw = (float2 *)(lds_rows + (size_t)(BLOCK / 64) * G);
+    double *acc = lds_rows + (size_t)wave_id() * G;
+    const uint32_t queues = gridDim.x < ROW_QUEUES ? gridDim.x : ROW_QUEUES, queue = blockIdx.x % queues;
+    uint32_t *ticket = tickets + queue * ROW_TICKET_STRIDE;
+    // a turn: asked for (lane 0 holds what the counter returns) and, a row later, read
+    auto ask = [&]() -> uint32_t { uint32_t t = 0; if (lane_id() == 0) t = atomicAdd(ticket, 1u); return t; };
+    auto turn_of = [&](uint32_t asked) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)asked) * queues + queue; };
+    uint32_t asked1 = ask(), asked2 = ask();
+    if constexpr (NFFT != 0) {
+        for (int q = threadIdx.x; q < NFFT; q += BLOCK) tw[q] = twiddle[q];
+        __syncthreads();                                // the only block-wide barrier
+    }
+    // what is known of a row before its walk
+    struct plan_t { row_runs t; bool crowded; };
+    auto plan_of = [&](uint32_t row) -> plan_t {
+        plan_t q{};
+        q.t = runs_of(rs, row_unit, row, g);
+        q.t.longest = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (q.t.unit[s] != NO_UNIT) { q.crowded = true; q.t.end[s] = q.t.beg[s]; }     // not walked here
+            const uint32_t len = q.t.end[s] - q.t.beg[s];
+            q.t.longest = len > q.t.longest ? len : q.t.longest;
+        }
+        return q;
+    };
+    uint32_t turn = turn_of(asked1);                    // rows are taken last first: turn u is row R - 1 - u
+    plan_t cur{};
+    if (turn < R) cur = plan_of(R - 1u - turn);
+    while (turn < R) {
+        const uint32_t row = R - 1u - turn;
+        const uint32_t next_turn = turn_of(asked2);
+        asked2 = ask();                                 // (for the row after the next)
+        plan_t nxt{};
+        if (next_turn < R) nxt = plan_of(R - 1u - next_turn);   // scalar loads on their way during this row's work
+        const row_runs &t = cur.t;
+        const bool crowded = cur.crowded;
+        if (t.longest == 0 && !crowded) {
+            emit_empty_row<NFFT>(density, spectrum, row, G, g.Ghp, g.sb, rows_marked);
+        } else {
+            const packed_runs p(t);
+            const bool packed = p.total <= PACKED_MAX;
+            uint32_t entry = 0;
+            if (crowded && lane_id() == 0) {
+                entry = atomicAdd(counters + COUNTER_ROWS, 1u);
+                heavy_rows[entry] = make_uint2(row, t.longest ? 1u : 0u);
+            }
+            if (t.longest != 0) {
+                light_t first{};
+                if (packed) first = p.load(F, key, 0);
+                for (int c = lane_id(); c < G; c += 64) acc[c] = 0.0;
+                if (packed) {
+                    deposit_packed(F, key, p, first, G, acc);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) deposit_chunks(F, key, t.beg[q], t.end[q], t.key0[q], q & 1, q & 2, G, acc);
+                }
+                pmfft::wave_sync();
+                if (crowded) {
+                    entry = __builtin_amdgcn_readfirstlane(entry);
+                    double *out = light_rows + (size_t)entry * G;
+                    for (int c = lane_id(); c < G; c += 64) out[c] = acc[c];
+                } else {
+                    emit_row<NFFT>(acc, tw, density, spectrum, row, G, g.Ghp, g.sb);
+                }
+                pmfft::wave_sync();                     // the row's LDS has been read: the next row may zero it
+            }
+        }
+        cur = nxt;
+        turn = next_turn;
+    }
 }
 
 // One wave per unit of a crowded source row: its particles into four LDS rows, written out as 4 G doubles
@@ -729,8 +836,8 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_un
     }
     // housekeeping of the last kernel of a deposit: the next deposit's counters (the other set: nobody uses it now)
     // start at zero, and the host learns how many units this one had (a word of page-locked host memory)
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        next_counters[threadIdx.x] = 0u;
+    if (blockIdx.x == 0) {
+        for (uint32_t q = threadIdx.x; q < COUNTER_WORDS; q += SUM_BLOCK) next_counters[q] = 0u;
         if (threadIdx.x == 0) *units_seen = counters[COUNTER_UNITS];
     }
     const uint32_t entries = counters[COUNTER_ROWS];
@@ -1181,13 +1288,16 @@ size_t pm_heavy_row_entries(int G, int64_t cap)
     return by_particles < rows ? by_particles : rows;
 }
 
+#ifndef PM_DEPOSIT_LOOP_PER_CU
+#define PM_DEPOSIT_LOOP_PER_CU 8
+#endif
 template <int NFFT>
 static hipError_t deposit_dispatch(pm_ctx *c)
 {
     const int G = c->g.G;
     const uint32_t R = (uint32_t)c->g.Gd * (uint32_t)G, Rs = (uint32_t)c->g.Gs * (uint32_t)G;
     // two sets of counters take turns: each deposit's last kernel zeroes the set of the next one
-    uint32_t *counters = c->counters + 64 * c->counter_set, *next_counters = c->counters + 64 * (1 - c->counter_set);
+    uint32_t *counters = c->counters + COUNTER_WORDS * c->counter_set, *next_counters = c->counters + COUNTER_WORDS * (1 - c->counter_set);
     c->counter_set = 1 - c->counter_set;
     hipError_t e = hipSuccess;
     // (a whole mesh whose rows leave as half-spectrum rows for the pass along y of this library: the empty rows are marked
@@ -1218,6 +1328,10 @@ static hipError_t deposit_dispatch(pm_ctx *c)
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void *)k_deposit_rows<NFFT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
             if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void *)k_deposit_rows_loop<NFFT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void *)k_deposit_rows_loop<NFFT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
+            if (e != hipSuccess) return e;
             allowed_rows.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -1237,6 +1351,25 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, counters,
                                                                   c->unit_rows, c->g);
     if (beside && (e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
+#ifndef PM_DEPOSIT_ONESHOT
+    {
+        // waves that stay: as many workgroups as the GPU holds at once (the LDS allows eight per CU), or fewer for a small mesh
+        pm_timer timed(c, PM_NSTAGES + PM_KERNEL_DEPOSIT_ROWS);
+        static int cus[64] = {};
+        int &ncu = cus[c->device & 63];
+        if (ncu == 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) ncu = 256;
+        const uint32_t want = (R + (BLOCK / 64) - 1) / (BLOCK / 64), most = (uint32_t)ncu * PM_DEPOSIT_LOOP_PER_CU;
+        const dim3 grid(want < most ? (want ? want : 1u) : most);
+        if (beside)
+            k_deposit_rows_loop<NFFT, false><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
+                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows,
+                counters + COUNTER_TICKETS);
+        else
+            k_deposit_rows_loop<NFFT, true><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
+                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows,
+                counters + COUNTER_TICKETS);
+    }
+#else
     {
         pm_timer timed(c, PM_NSTAGES + PM_KERNEL_DEPOSIT_ROWS);
         const dim3 grid((R + BLOCK / 64 - 1) / (BLOCK / 64));
@@ -1248,6 +1381,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
             k_deposit_rows<NFFT, true><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
                 c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
     }
+#endif
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
     k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
                                                                                         c->light_rows, c->density, c->spectrum, c->twiddle, c->g,
