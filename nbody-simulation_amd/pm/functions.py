@@ -138,6 +138,7 @@ def compute_kinetic_energy(velocities, masses):
     velocities = np.asarray(velocities)
     sim = _engine(2, 1.0, len(velocities))
     sim.set_particles(np.zeros((len(velocities), 3), np.float32), velocities, masses)
+    sim.set_mesh(L.MESH_POTENTIAL, np.zeros((2, 2, 2), np.float32))     # (pm_energies sums both energies and wants a potential for the other)
     return sim.energies()[0]
 
 
