@@ -122,7 +122,7 @@ def kernel_bytes(n, m, fused=True):
     position and velocity (48N) and reads the potential once (4M; in the staged pipeline the three gradient meshes,
     12M).  The sort passes and the reorder have no algorithmic bytes (cell order is not part of 64N + 80M): they are
     reported with their durations only and cannot be the roofline kernel."""
-    return {"deposit_rows": ("k_deposit_rows", 16 * n + 4 * m), "col_y_fwd": ("k_col_fft<G, -1, false>", 8 * m),
+    return {"deposit_rows": ("k_deposit_rows_loop", 16 * n + 4 * m), "col_y_fwd": ("k_col_fft<G, -1, false>", 8 * m),
             "col_x_green": ("k_col_fft<G, -1, true>", 8 * m), "col_y_inv": ("k_col_fft<G, 1, false>", 8 * m),
             "row_inv": ("k_row_c2r", 8 * m), "gather": ("k_gather", 48 * n + (4 * m if fused else 12 * m)),
             "sort_pass": ("k_radix_pass", 0), "reorder": ("k_reorder", 0)}
@@ -140,19 +140,21 @@ def fused_stage_bytes(n, m):
 
 
 # kernels that make up each timed stage (substrings of the names rocprofv3 reports)
-STAGE_KERNELS = {"bin": ["k_radix_pass", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start", "k_cell_keys", "fillBuffer", "k_clear"],
+STAGE_KERNELS = {"bin": ["k_radix_pass", "k_tile_counts", "k_chunk_sums", "k_scan_chunks", "k_digit_counts", "k_digit_offsets", "k_reorder", "k_row_start",
+                         "k_cell_keys", "fillBuffer", "k_clear", "k_scan_movers", "k_compact_movers", "k_place_movers", "k_tile_first", "k_place_stayers",
+                         "k_row_start_update"],
                  "deposit": ["k_deposit_rows", "k_deposit_units", "k_sum_units"],
                  "fft_fwd": ["k_row_r2c", "k_col_fft<512, -1, false>"], "green": ["k_col_fft<512, -1, true>", "k_green"],
                  "fft_inv": ["k_col_fft<512, 1, false>", "k_row_c2r"], "gradient": ["k_gradient"], "gather": ["k_gather"]}
 
 
-def measured_traffic(names, per_launch=False):
+def measured_traffic(names, per_launch=False, workload="two_galaxy"):
     """HBM bytes of the kernels whose names contain one of `names`, from the newest committed rocprofv3 counter passes
-    of the headline workload (profiles/r*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB
-    units, FETCH_SIZE doubled for gfx950's half-counted wide reads): per step, or per launch of the kernel.  None if
-    there is no such file or kernel."""
+    of the headline workload (profiles/r*_pmc_traffic.json; the uniform set of the same size: r*_pmc_traffic_uniform.json:
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units, FETCH_SIZE doubled for gfx950's half-counted wide
+    reads): per step, or per launch of the kernel.  None if there is no such file or kernel."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json" if workload == "two_galaxy" else f"r*_pmc_traffic_{workload}.json")))
     if not files:
         return None
     with open(files[-1]) as f:
@@ -352,7 +354,9 @@ def main():
             ue = time.perf_counter() - t0
         also = {"workload": f"uniform N={n} G={G} L={L} dt={DT}", "value": n * args.steps / ue, "unit": "particle-updates/s",
                 "ms_per_step": ue / args.steps * 1e3,
-                "step_roofline_frac": (64 * n + 80 * m) / (ue / args.steps) / 1e9 / HBM_PEAK_GBPS}
+                "step_roofline_frac": (64 * n + 80 * m) / (ue / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                # its longest kernel is the gather (particles spread over the whole mesh): HBM bytes per launch from the counter passes
+                "gather_traffic": measured_traffic(["k_gather"], per_launch=True, workload="uniform") if n == 16_777_216 and G == 512 else None}
         del up, uv, um
 
     if rank == 0:
@@ -367,9 +371,9 @@ def main():
         dom = max((k for k in kb if kb[k][1] > 0), key=lambda k: kper[k])
         dom_name, dom_bytes = kb[dom][0].replace("<G,", f"<{G},"), kb[dom][1]
         ach = dom_bytes / (kper[dom] * 1e-3) / 1e9 if kper[dom] > 0 else 0.0
-        headline = args.workload == "two_galaxy" and n == 16_777_216 and G == 512
+        headline = args.workload in ("two_galaxy", "uniform") and n == 16_777_216 and G == 512       # (sets the counter passes were run on)
         b_step, b_pipe = 64 * n + 80 * m, 64 * n + (40 * m if custom else 80 * m)
-        bin_traffic = measured_traffic(STAGE_KERNELS["bin"]) if headline else None
+        bin_traffic = measured_traffic(STAGE_KERNELS["bin"], workload=args.workload) if headline else None
         out = {
             "metric": metric_name(args),
             "value": world * n * args.steps / elapsed, "unit": "particle-updates/s",
@@ -381,7 +385,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic([kb[dom][0].split("<")[0]], per_launch=True) if headline else None,
+                         "traffic": measured_traffic([kb[dom][0].split("<")[0]], per_launch=True, workload=args.workload) if headline else None,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": kper[dom],
                          "launches_timed": kernels[dom][1],
                          # the two longest launches are within a few microseconds of each other on this workload and

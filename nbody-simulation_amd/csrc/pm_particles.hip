@@ -702,8 +702,8 @@ k_deposit_rows(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
 // the places of the next row's runs one row ahead, so that both are there when the row before is done.
 constexpr uint32_t ROW_TICKET_STRIDE = 32, ROW_QUEUES = PM_ROW_QUEUES;      // words between two counters (a 128-byte line each)
 
-template <int NFFT, bool TIGHT>
-__global__ void __launch_bounds__(BLOCK, TIGHT ? 8 : 1)
+template <int NFFT>
+__global__ void __launch_bounds__(BLOCK)
 k_deposit_rows_loop(const pm_frac *__restrict__ F, const uint32_t *__restrict__ key,
                     const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, float *__restrict__ density,
                     float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle,
@@ -719,6 +719,8 @@ k_deposit_rows_loop(const pm_frac *__restrict__ F, const uint32_t *__restrict__ 
     uint32_t *ticket = tickets + queue * ROW_TICKET_STRIDE;
     // a turn: asked for (lane 0 holds what the counter returns) and, a row later, read
     auto ask = [&]() -> uint32_t { uint32_t t = 0; if (lane_id() == 0) t = atomicAdd(ticket, 1u); return t; };
+    // (Measured and not kept: turns 4 t .. 4 t + 3 of a counter as four rows that follow each other, so that the waves that
+    // feed on the same mesh rows of particles share an XCD's L2: 355 instead of 293 us on the clustered set.)
     auto turn_of = [&](uint32_t asked) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)asked) * queues + queue; };
     uint32_t asked1 = ask(), asked2 = ask();
     if constexpr (NFFT != 0) {
@@ -1328,9 +1330,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute((const void *)k_deposit_rows<NFFT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
             if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void *)k_deposit_rows_loop<NFFT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute((const void *)k_deposit_rows_loop<NFFT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
+            e = hipFuncSetAttribute((const void *)k_deposit_rows_loop<NFFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_rows + tw_bytes));
             if (e != hipSuccess) return e;
             allowed_rows.fetch_or(bit, std::memory_order_release);
         }
@@ -1351,37 +1351,39 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, counters,
                                                                   c->unit_rows, c->g);
     if (beside && (e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
-#ifndef PM_DEPOSIT_ONESHOT
-    {
-        // waves that stay: as many workgroups as the GPU holds at once (the LDS allows eight per CU), or fewer for a small mesh
-        pm_timer timed(c, PM_NSTAGES + PM_KERNEL_DEPOSIT_ROWS);
-        static int cus[64] = {};
-        int &ncu = cus[c->device & 63];
-        if (ncu == 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) ncu = 256;
-        const uint32_t want = (R + (BLOCK / 64) - 1) / (BLOCK / 64), most = (uint32_t)ncu * PM_DEPOSIT_LOOP_PER_CU;
-        const dim3 grid(want < most ? (want ? want : 1u) : most);
-        if (beside)
-            k_deposit_rows_loop<NFFT, false><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
-                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows,
-                counters + COUNTER_TICKETS);
-        else
-            k_deposit_rows_loop<NFFT, true><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
-                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows,
-                counters + COUNTER_TICKETS);
-    }
+    // Two row kernels.  A set with crowded rows (the units run beside) takes the one whose waves stay and take rows in turn:
+    // its rows differ a hundredfold in what they cost, and half of a wave-per-row kernel's time is the start of waves that
+    // then find little to do (headline set: step 2.00 -> 1.97 ms).  A set without crowded rows takes a wave per row, held to
+    // 64 registers: all its rows are alike, eight waves per SIMD hide their waits, and the looping kernel at that register
+    // budget spills (uniform set of the same size: 354 us against 506).  The word that decides is a step or two old, as
+    // for the units: either kernel is right for any set.
+#ifdef PM_DEPOSIT_ONESHOT
+    const bool looping = false;
 #else
+    const bool looping = beside;
+#endif
     {
         pm_timer timed(c, PM_NSTAGES + PM_KERNEL_DEPOSIT_ROWS);
-        const dim3 grid((R + BLOCK / 64 - 1) / (BLOCK / 64));
-        // (no crowded rows lately -- the same word that decides where the units run: the instantiation for such sets)
-        if (beside)
-            k_deposit_rows<NFFT, false><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
-                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
-        else
-            k_deposit_rows<NFFT, true><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
-                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
+        if (looping) {
+            // as many workgroups as the GPU holds at once (the LDS allows eight per CU), or fewer for a small mesh
+            static int cus[64] = {};
+            int &ncu = cus[c->device & 63];
+            if (ncu == 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) ncu = 256;
+            const uint32_t want = (R + (BLOCK / 64) - 1) / (BLOCK / 64), most = (uint32_t)ncu * PM_DEPOSIT_LOOP_PER_CU;
+            const dim3 grid(want < most ? (want ? want : 1u) : most);
+            k_deposit_rows_loop<NFFT><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
+                c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows,
+                counters + COUNTER_TICKETS);
+        } else {
+            const dim3 grid((R + BLOCK / 64 - 1) / (BLOCK / 64));
+            if (beside)
+                k_deposit_rows<NFFT, false><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
+                    c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
+            else
+                k_deposit_rows<NFFT, true><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
+                    c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
+        }
     }
-#endif
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
     k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
                                                                                         c->light_rows, c->density, c->spectrum, c->twiddle, c->g,

@@ -30,19 +30,25 @@ def per_kernel(d, counter):
     return tot, n
 
 
-rd, nrd = per_kernel("fetch", "FETCH_SIZE")
-wr, _ = per_kernel("write", "WRITE_SIZE")
-kernels = {}
-for k in sorted(set(rd) | set(wr)):
-    kernels[k] = {"launches_per_step": len(nrd.get(k, ())) / STEPS,
-                  "read_bytes_per_step": 2 * rd.get(k, 0.0) * 1024 / STEPS,
-                  "write_bytes_per_step": wr.get(k, 0.0) * 1024 / STEPS}
-out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python bench.py --steps 3 --warmup 1 "
-               "--cpu-baseline skip` (two_galaxy, N=16777216, G=512). Counter unit KiB. read_bytes = 2 * FETCH_SIZE * 1024 "
-               "(gfx950 counts a wide coalesced read at half), write_bytes = WRITE_SIZE * 1024. per_step = sum over all "
-               f"launches / {STEPS} steps.", "steps": STEPS, "kernels": kernels}
-json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
-tot = sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for k, v in kernels.items() if "pack" not in k and "cell_keys" not in k)
-print(f"HBM traffic per step: {tot / 1e9:.2f} GB")
-for k, v in sorted(kernels.items(), key=lambda kv: -(kv[1]["read_bytes_per_step"] + kv[1]["write_bytes_per_step"]))[:14]:
-    print(f"{k[:70]:70s} rd {v['read_bytes_per_step'] / 1e6:9.1f} MB  wr {v['write_bytes_per_step'] / 1e6:9.1f} MB  x{v['launches_per_step']:.2f}")
+def traffic(fetch_dir, write_dir, workload, path):
+    rd, nrd = per_kernel(fetch_dir, "FETCH_SIZE")
+    wr, _ = per_kernel(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(rd) | set(wr)):
+        kernels[k] = {"launches_per_step": len(nrd.get(k, ())) / STEPS,
+                      "read_bytes_per_step": 2 * rd.get(k, 0.0) * 1024 / STEPS,
+                      "write_bytes_per_step": wr.get(k, 0.0) * 1024 / STEPS}
+    out = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python bench.py --steps 3 --warmup 1 "
+                   f"--cpu-baseline skip` ({workload}, N=16777216, G=512). Counter unit KiB. read_bytes = 2 * FETCH_SIZE * 1024 "
+                   "(gfx950 counts a wide coalesced read at half), write_bytes = WRITE_SIZE * 1024. per_step = sum over all "
+                   f"launches / {STEPS} steps.", "steps": STEPS, "kernels": kernels}
+    json.dump(out, open(path, "w"), indent=1)
+    tot = sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for k, v in kernels.items() if "pack" not in k and "cell_keys" not in k)
+    print(f"{workload}: HBM traffic per step: {tot / 1e9:.2f} GB")
+    for k, v in sorted(kernels.items(), key=lambda kv: -(kv[1]["read_bytes_per_step"] + kv[1]["write_bytes_per_step"]))[:16]:
+        print(f"{k[:70]:70s} rd {v['read_bytes_per_step'] / 1e6:9.1f} MB  wr {v['write_bytes_per_step'] / 1e6:9.1f} MB  x{v['launches_per_step']:.2f}")
+
+
+traffic("fetch", "write", "two_galaxy", f"profiles/{tag}_pmc_traffic.json")
+if glob.glob(raw + "/fetch_uniform/**/*counter_collection.csv", recursive=True):
+    traffic("fetch_uniform", "write_uniform", "uniform", f"profiles/{tag}_pmc_traffic_uniform.json")
