@@ -50,7 +50,8 @@ struct col_pass {
     float soft;                 // pm_geom::soft
     int outer0;             // mesh index of outer index 0 (Green multiply)
     int tile0;              // first column tile of this launch (a launch may cover a range of tiles only)
-    int ntiles;             // column tiles per outer index in this launch
+    int ntiles;             // column tiles per outer index in this launch (without the ones counted by `lone`)
+    int lone;               // workgroups at the start of the launch that take the last tile of C outer indices each
     // BLK != 0 (slab decomposition, transform along y): the other side of the pass is not `spec` but the buffer of an
     // all-to-all, `blocks`, laid out (G / Gs, Gs planes, Gs rows, pitch): row y of plane `outer` lies in block y / Gs
     float2 *blocks;
@@ -91,6 +92,11 @@ template <int N, int DIR, bool GREEN> struct col_plan {
     static constexpr int NB1 = (N / R1) / TPC;          // butterflies per thread in stage 1
     static constexpr int NB = (N / 8) / TPC;            // ... in stages 2 and 3 (= 4)
     static constexpr size_t LDS_BYTES = (size_t)(N * C + N) * sizeof(float2);
+    // waves per SIMD that the registers must leave room for: what the LDS lets a CU hold (two workgroups of 16 waves for the
+    // passes along j at N = 512, two of 8 waves for the fused pass and up to N = 1024, one of 8 waves at N = 2048).  The
+    // kernels fit without it; the bound is there for the rarely taken LONE path, which may spill rather than cost the
+    // whole kernel a workgroup per CU.
+    static constexpr int MIN_WAVES = (N == 512 && !GREEN) ? 8 : N <= 1024 ? 4 : 2;
 };
 
 // Thread t owns column c = t % C of its workgroup's C columns; jl = t / C is its place among the column's threads.  Stage 1
@@ -100,24 +106,22 @@ template <int N, int DIR, bool GREEN> struct col_plan {
 // BLK = 1: the results go to p.blocks instead of back to p.spec; BLK = 2: the inputs come from p.blocks; BLK = 3 (Green
 // pass only): the multiply includes the Gaussian softening factor exp(-p.soft k2) -- an instantiation of its own, so that
 // the pass without softening stays the code it was (as a run-time branch the factor cost that pass 6 %).
-template <int N, int DIR, bool GREEN, int BLK = 0>
-__global__ void __launch_bounds__((col_plan<N, DIR, GREEN>::THREADS))
-k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
+//
+// With G/2 + 1 = 16 q + 1 columns the last tile of every outer index holds one column, G/2, and fifteen that do not exist.
+// Those tiles are taken C outer indices at a time instead (LONE: the p.lone first workgroups of the launch; thread column
+// c works on column G/2 of outer index C * n + c), which saves one tile in q + 1 for the same memory accesses.
+template <int N, int DIR, bool GREEN, int BLK, bool LONE>
+__device__ __forceinline__ void col_tile(const col_pass &p, const float2 *__restrict__ twiddle, float2 *lds, int lb)
 {
     using plan = col_plan<N, DIR, GREEN>;
     constexpr int C = plan::C, R1 = plan::R1, TPC = plan::TPC, NB1 = plan::NB1, NB = plan::NB, Q = N / 8;
-    extern __shared__ float2 lds[];                 // [N][C] tile, then the N twiddles
-    float2 *tile = lds;
+    float2 *tile = lds;                             // [N][C] tile, then the N twiddles
     float2 *tw = lds + N * C;
     const int t = threadIdx.x, c = t & (C - 1), jl = t / C;
-    // S = 16 / C workgroups share a 16-column tile.  The hardware hands workgroup b to XCD b % 8: the two halves of a
-    // tile are given to workgroups b and b + 8, so that the 128-byte lines they share are fetched into one L2.
     constexpr int S = COLS / C;
-    int lb = blockIdx.x;
-    if (S == 2 && (lb | 15) < (int)gridDim.x) lb = (lb & ~15) + 2 * (lb & 7) + ((lb >> 3) & 1);
     const int per_outer = p.ntiles * S;
-    const int outer = lb / per_outer, sub = lb % per_outer;
-    const int col = p.tile0 * COLS + sub * C + c;
+    const int outer = LONE ? lb * C + c : lb / per_outer;
+    const int col = LONE ? p.ncols - 1 : p.tile0 * COLS + (lb % per_outer) * C + c;
     const bool valid = col < p.ncols;
     float2 *g = p.spec + (int64_t)(outer >> p.o_shift) * p.o_hi + (int64_t)(outer & ((1 << p.o_shift) - 1)) * p.o_lo + col;
     auto in_spec = [&](int row) -> float2 & {
@@ -248,6 +252,26 @@ k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
     }
 }
 
+template <int N, int DIR, bool GREEN, int BLK = 0>
+__global__ void __launch_bounds__((col_plan<N, DIR, GREEN>::THREADS), (col_plan<N, DIR, GREEN>::MIN_WAVES))
+k_col_fft(col_pass p, const float2 *__restrict__ twiddle)
+{
+    extern __shared__ float2 lds[];
+    // S = 16 / C workgroups share a 16-column tile.  The hardware hands workgroup b to XCD b % 8: the two halves of a
+    // tile are given to workgroups b and b + 8, so that the 128-byte lines they share are fetched into one L2.
+    constexpr int S = COLS / col_plan<N, DIR, GREEN>::C;
+    // (the lone tiles first: at the end of the launch they would be a round of their own)
+    int lb = blockIdx.x;
+    if (lb < p.lone) {
+        col_tile<N, DIR, GREEN, BLK, true>(p, twiddle, lds, lb);
+        return;
+    }
+    lb -= p.lone;
+    const int full = (int)gridDim.x - p.lone;
+    if (S == 2 && (lb | 15) < full) lb = (lb & ~15) + 2 * (lb & 7) + ((lb >> 3) & 1);
+    col_tile<N, DIR, GREEN, BLK, false>(p, twiddle, lds, lb);
+}
+
 // ---- z axis: real <-> half-complex transforms of contiguous rows ----------------------------------
 //
 // One wave per mesh row.  A row of N reals is read as M = N/2 complex numbers z[n] = x[2n] + i x[2n+1],
@@ -329,7 +353,15 @@ hipError_t launch_col(pm_ctx *c, const col_pass &p, int blocks)
             allowed.fetch_or(bit, std::memory_order_release);
         }
     }
-    k_col_fft<N, DIR, GREEN, BLK><<<blocks * (COLS / col_plan<N, DIR, GREEN>::C), col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(p, c->twiddle);
+    constexpr int C = col_plan<N, DIR, GREEN>::C;
+    col_pass q = p;
+    const int outers = p.ntiles > 0 ? blocks / p.ntiles : 0;
+#ifndef PM_COL_NO_LONE
+    if (p.ncols % COLS == 1 && p.tile0 + p.ntiles == p.tiles && outers > 0 && outers % C == 0) { q.lone = outers / C; q.ntiles -= 1; }
+#endif
+    const int grid = outers * q.ntiles * (COLS / C) + q.lone;
+    if (grid == 0) return hipSuccess;
+    k_col_fft<N, DIR, GREEN, BLK><<<grid, col_plan<N, DIR, GREEN>::THREADS, col_plan<N, DIR, GREEN>::LDS_BYTES, c->stream>>>(q, c->twiddle);
     return hipGetLastError();
 }
 
