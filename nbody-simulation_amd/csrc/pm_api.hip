@@ -109,8 +109,7 @@ int ensure_binned(pm_ctx *c)
     HIP_TRY(c, pm_settle_velocities(c));        // src is about to be overwritten
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
     TRY(pm_bin_order(c, bits_for(c->g.M)));
-    HIP_TRY(c, pm_launch_reorder(c));
-    if (!c->last_incremental) HIP_TRY(c, pm_launch_row_start(c));       // (the other way of binning has brought them up to date itself)
+    HIP_TRY(c, pm_launch_reorder(c, !c->last_incremental));     // (with the row starts, unless the binning from the order before has brought them up to date itself)
     c->binned = true;
     c->order_known = true;
     c->order_n = c->n;
@@ -408,6 +407,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
         HIP_TRY(c, pm_launch_pack(c, nullptr, nullptr, vel ? st : nullptr));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    if (c->units_seen) *c->units_seen = 1;              // a new set: crowded rows are planned for until a deposit has counted none
     return PM_OK;
 }
 
@@ -446,6 +446,7 @@ int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *par
         c->n = n;
         HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->units_seen) *c->units_seen = 1;
         return PM_OK;
     }
     // a slab: every rank draws all n numbers and keeps the particles of its window, in the order of their numbers --

@@ -254,7 +254,7 @@ size_t pm_sort_counted_tmp_bytes(int64_t n_max);
 hipError_t pm_sort_pairs_counted(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n_max,
                                  const uint32_t *n_dev, int bits, int device, hipStream_t s);
 hipError_t pm_launch_clear(void *p, size_t bytes, hipStream_t s);      // zero-fill by a kernel (bytes and p multiples of 16)
-hipError_t pm_launch_reorder(pm_ctx *c);
+hipError_t pm_launch_reorder(pm_ctx *c, bool row_starts);
 size_t pm_sort_tmp_bytes(int64_t cap);
 hipError_t pm_settle_velocities(pm_ctx *c);     // must run before src is overwritten by a new sort
 hipError_t pm_launch_row_start(pm_ctx *c);

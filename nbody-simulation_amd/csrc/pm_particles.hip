@@ -9,6 +9,7 @@
 #include "pm_fft_dev.hpp"
 
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 #include "pm_cell_dev.hpp"
 
@@ -170,9 +171,14 @@ __global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__res
 #ifndef PM_REORDER_XCD
 #define PM_REORDER_XCD 64
 #endif
+// rs != nullptr: the kernel also writes row_start (see k_row_start) from the sorted keys: the thread of slot r, whose key
+// lies in mesh row b while the key before it lies in row a < b, writes rs[a + 1 .. b] = r (the thread of slot 0: rs[0 .. b]
+// = 0, the thread of the last slot also rs[b + 1 .. R] = n).  Stretches of more than a few rows -- empty regions of the
+// mesh -- are written by the whole wave.
 template <typename TP>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
-                          pm_frac *__restrict__ F, const uint32_t *__restrict__ src, int64_t n, pm_geom g)
+                          pm_frac *__restrict__ F, const uint32_t *__restrict__ src, int64_t n, pm_geom g,
+                          const uint32_t *__restrict__ key, uint32_t R, uint32_t *__restrict__ rs)
 {
     uint32_t blk = blockIdx.x;
     if constexpr (PM_REORDER_XCD < 0) {                 // every XCD one contiguous eighth of the slots
@@ -180,10 +186,36 @@ __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__re
         if (blk < per * 8u) blk = (blk & 7u) * per + (blk >> 3);
     } else blk = xcd_block<PM_REORDER_XCD>();
     int64_t r = (int64_t)blk * BLOCK + threadIdx.x;
-    if (r >= n) return;
-    const pm_prec<TP> rec = Pin[src[r]];
-    Pout[r] = rec;
-    F[r] = pmcell::fraction_record(rec, g);
+    const bool live = r < n;
+    if (rs == nullptr && !live) return;
+    if (live) {
+        const pm_prec<TP> rec = Pin[src[r]];
+        Pout[r] = rec;
+        F[r] = pmcell::fraction_record(rec, g);
+    }
+    if (rs == nullptr) return;
+    // (every lane of the wave stays for the stretches the wave writes together)
+    const uint32_t G = (uint32_t)g.G, at = (uint32_t)r;
+    uint32_t own = 0, first = 0, count = 0, tail = 0;   // rows first .. first + count - 1 take r; the `tail` rows after row `own` take n
+    if (live) {
+        own = key[r] / G;
+        first = r == 0 ? 0u : key[r - 1] / G + 1u;
+        count = own + 1u - first;
+        if (r == n - 1) tail = R - own;
+    }
+    if (count <= 4u) {
+        for (uint32_t q = 0; q < count; ++q) rs[first + q] = at;
+        count = 0;
+    }
+    unsigned long long m = __ballot(count != 0u || tail != 0u);
+    const uint32_t lane = (uint32_t)lane_id();
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const uint32_t f = __shfl(first, l), c = __shfl(count, l), v = __shfl(at, l), after = __shfl(own, l) + 1u, t = __shfl(tail, l);
+        for (uint32_t q = lane; q < c; q += 64u) rs[f + q] = v;
+        for (uint32_t q = lane; q < t; q += 64u) rs[after + q] = (uint32_t)n;
+    }
 }
 
 // row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
@@ -236,7 +268,8 @@ constexpr int UNIT_BLOCK = 128;         // two waves, each with four LDS rows
 #define PM_ROW_QUEUES 64
 #endif
 // counters[]: units handed out, density rows listed (own 128-byte lines), then the turn counters of the row kernel (a line each)
-constexpr int COUNTER_UNITS = 0, COUNTER_ROWS = 32, COUNTER_TICKETS = 64;
+// (COUNTER_PLANNED: workgroups of k_plan_units that are done, where that kernel is a deposit's only one beside the rows')
+constexpr int COUNTER_UNITS = 0, COUNTER_PLANNED = 1, COUNTER_ROWS = 32, COUNTER_TICKETS = 64;
 constexpr uint32_t COUNTER_WORDS = 64 + PM_ROW_QUEUES * 32;         // words of one set of counters
 
 __device__ __forceinline__ void lds_add(double *p, double v)
@@ -561,8 +594,13 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
 // row_live (may be null; whole meshes only, G a multiple of 64): a bit per DENSITY row, set where one of the four mesh rows
 // that feed it holds a particle.  Where it is written, the deposit writes nothing for the other rows and the transform
 // along y that follows takes them as zeros without reading them.
+// plan = false: the units are counted but none is planned (row_unit = NO_UNIT everywhere: the row kernel walks every source
+// itself, and neither k_deposit_units nor k_sum_units is launched).  The workgroup that finishes last then does the
+// housekeeping that is k_sum_units' otherwise: the next deposit's counters start at zero, and the host learns how many units
+// there would have been.
 __global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32_t *__restrict__ row_unit, uint32_t *__restrict__ unit_src,
-                             uint32_t *__restrict__ counters, unsigned long long *__restrict__ row_live, uint32_t G)
+                             uint32_t *__restrict__ counters, unsigned long long *__restrict__ row_live, uint32_t G, bool plan,
+                             uint32_t *__restrict__ next_counters, volatile uint32_t *__restrict__ units_seen)
 {
     const uint32_t row = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t len = row < R ? rs[row + 1] - rs[row] : 0u;
@@ -590,10 +628,25 @@ __global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32
         if (lane_id() == 0) base = atomicAdd(counters + COUNTER_UNITS, total);
         base = __shfl(base, 0);
     }
-    if (row >= R) return;
-    const uint32_t first = base + before - units;
-    row_unit[row] = units ? first : NO_UNIT;
-    for (uint32_t u = 0; u < units; ++u) unit_src[first + u] = row;
+    if (plan) {
+        if (row >= R) return;
+        const uint32_t first = base + before - units;
+        row_unit[row] = units ? first : NO_UNIT;
+        for (uint32_t u = 0; u < units; ++u) unit_src[first + u] = row;
+        return;
+    }
+    if (row < R) row_unit[row] = NO_UNIT;
+    __shared__ uint32_t last;
+    __syncthreads();                                    // the workgroup's counts have been added
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(counters + COUNTER_PLANNED, 1u) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x == 0) *units_seen = __hip_atomic_load(counters + COUNTER_UNITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t q = threadIdx.x; q < COUNTER_WORDS; q += BLOCK) next_counters[q] = 0u;
 }
 
 // One wave per density row.  A row with a crowded source leaves that source out and is listed for
@@ -1259,17 +1312,30 @@ static hipError_t settle_velocities(pm_ctx *c)
     return hipGetLastError();
 }
 
-hipError_t pm_launch_reorder(pm_ctx *c)
+// row_starts: row_start is brought up to date as well (by the same kernel or by pm_launch_row_start)
+#ifndef PM_ROW_STARTS_FUSED_MAX
+#define PM_ROW_STARTS_FUSED_MAX (1 << 22)
+#endif
+hipError_t pm_launch_reorder(pm_ctx *c, bool row_starts)
 {
     int64_t n = c->n;
-    if (n == 0) return hipSuccess;
+    if (n == 0) return row_starts ? pm_launch_row_start(c) : hipSuccess;
     int u = c->cur, w = 1 - u;
     pm_timer timed(c, PM_NSTAGES + PM_KERNEL_REORDER);
-    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g);
-    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g);
+    // (with the row starts: rows of the owned planes, as pm_launch_row_start)
+    const uint32_t R = (uint32_t)c->g.Gs * (uint32_t)c->g.G;
+    // Up to a few million particles the row starts come out of the reorder kernel (1M particles on 128^3: one launch of 7 us
+    // less in a step of 0.19 ms); for more a kernel of their own is faster than what they cost the reorder, which is
+    // at its memory bandwidth (16.7M particles: 16 us against 22).
+    const bool fused = row_starts && n <= PM_ROW_STARTS_FUSED_MAX;
+    uint32_t *rs = fused ? c->row_start : nullptr;
+    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g, c->key_out, R, rs);
+    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g, c->key_out, R, rs);
     c->cur = w;
     c->v_stale = true;
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && row_starts && !fused) e = pm_launch_row_start(c);
+    return e;
 }
 
 hipError_t pm_settle_velocities(pm_ctx *c) { return settle_velocities(c); }
@@ -1307,7 +1373,15 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     // (grid sizes whose pass along y has a thread read rows jl, jl + 64, ...: one word of the marks per row read)
     const bool mark_rows = (NFFT == 512 || NFFT == 1024) && !c->slab && c->row_live != nullptr;
     c->rows_marked = mark_rows;
-    k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, counters, mark_rows ? c->row_live : nullptr, (uint32_t)G);
+    // Crowded rows are planned as units only while recent deposits had some (the count comes back to the host without anyone
+    // waiting for it, so it is a step or two old): a set without them -- a uniform one -- then runs two kernels instead of
+    // four.  Should crowded rows appear, the row kernel walks them itself, slowly but with the same sums, and the count
+    // that comes back switches the units on for the deposits that follow (a new particle set starts with them on).
+    // (PM_DEPOSIT_UNITS in the environment, read at every deposit: "0" never plans units, anything else always -- tests)
+    const char *forced = std::getenv("PM_DEPOSIT_UNITS");
+    const bool planned = forced ? forced[0] != '0' : *c->units_seen != 0;
+    k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, counters, mark_rows ? c->row_live : nullptr, (uint32_t)G,
+                                                       planned, next_counters, c->units_seen_dev);
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
     const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);
@@ -1335,21 +1409,20 @@ static hipError_t deposit_dispatch(pm_ctx *c)
             allowed_rows.fetch_or(bit, std::memory_order_release);
         }
     }
-    // The units need the plan only: they are summed on the side stream while the rows are walked on this one --
-    // unless recent deposits had no units at all (the count comes back to the host without anyone waiting for
-    // it, so it is a step or two old: good enough to decide where to launch a kernel that finds out for itself).
+    // The units need the plan only: they are summed on the side stream while the rows are walked on this one.
 #ifdef PM_NO_BESIDE
     const bool beside = false;                          // (tuning builds: each kernel's own duration)
 #else
-    const bool beside = *c->units_seen != 0;
+    const bool beside = planned;
 #endif
     hipStream_t us = beside ? c->side : c->stream;
     if (beside) {
         if ((e = hipEventRecord(c->ev_fork, c->stream)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
     }
-    k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, counters,
-                                                                  c->unit_rows, c->g);
+    if (planned)
+        k_deposit_units<<<PM_UNIT_GRID, UNIT_BLOCK, lds_units, us>>>(c->frac, c->key_out, c->row_start, c->row_unit, c->unit_src, counters,
+                                                                      c->unit_rows, c->g);
     if (beside && (e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
     // Two row kernels.  A set with crowded rows (the units run beside) takes the one whose waves stay and take rows in turn:
     // its rows differ a hundredfold in what they cost, and half of a wave-per-row kernel's time is the start of waves that
@@ -1360,7 +1433,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
 #ifdef PM_DEPOSIT_ONESHOT
     const bool looping = false;
 #else
-    const bool looping = beside;
+    const bool looping = planned;
 #endif
     {
         pm_timer timed(c, PM_NSTAGES + PM_KERNEL_DEPOSIT_ROWS);
@@ -1376,7 +1449,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
                 counters + COUNTER_TICKETS);
         } else {
             const dim3 grid((R + BLOCK / 64 - 1) / (BLOCK / 64));
-            if (beside)
+            if (planned)
                 k_deposit_rows<NFFT, false><<<grid, BLOCK, lds_rows + tw_bytes, c->stream>>>(
                     c->frac, c->key_out, c->row_start, c->row_unit, c->density, c->spectrum, c->twiddle, c->heavy_rows, counters, c->light_rows, c->g, mark_rows);
             else
@@ -1385,6 +1458,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
         }
     }
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
+    if (planned)
     k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
                                                                                         c->light_rows, c->density, c->spectrum, c->twiddle, c->g,
                                                                                         next_counters, c->units_seen_dev);

@@ -119,8 +119,7 @@ int ensure_binned(pm_ctx *c)
     if (!c->keys_fresh) HIP_TRY(c, pm_launch_cell_keys(c));
     // one key more than the slab has cells: "not mine" -- which a slab that is the whole mesh never hands out
     TRY(pm_bin_order(c, bits_for((int64_t)c->g.Gs * c->g.G * c->g.G + (c->g.Gs != c->g.G ? 1 : 0))));
-    HIP_TRY(c, pm_launch_reorder(c));
-    if (!c->last_incremental) HIP_TRY(c, pm_launch_row_start(c));       // (the other way of binning has brought them up to date itself)
+    HIP_TRY(c, pm_launch_reorder(c, !c->last_incremental));     // (with the row starts, unless the binning from the order before has brought them up to date itself)
     c->n -= c->leaving;         // they carry the last key: the tail of the cell order
     c->leaving = 0;
     c->binned = true;

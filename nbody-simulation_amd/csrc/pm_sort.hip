@@ -592,15 +592,16 @@ hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, si
     return hipGetLastError();
 }
 
-// Sorts of fewer tiles than this keep the look-back chain (fewer launches).  The environment variable
+// Sorts of fewer tiles than this (one per CU: all of them start at once) keep the look-back chain: six launches a sort
+// instead of twelve, and at 1M pairs the same time.  The environment variable
 // PM_SORT_CHAIN_TILES sets another bound (tests: 0 sends every sort the other way, a huge value none).
 unsigned chain_below_tiles()
 {
     const char *v = std::getenv("PM_SORT_CHAIN_TILES");
-    if (!v) return 64u;
+    if (!v) return 256u;
     char *end = nullptr;
     const unsigned long long m = std::strtoull(v, &end, 10);
-    return end != v ? (unsigned)(m > 0xffffffffull ? 0xffffffffull : m) : 64u;
+    return end != v ? (unsigned)(m > 0xffffffffull ? 0xffffffffull : m) : 256u;
 }
 
 // Sorts n (key, value) pairs by the low `bits` bits of the keys, values going in as 0, 1, 2, ... (vin == nullptr) or

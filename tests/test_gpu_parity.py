@@ -573,6 +573,36 @@ def test_deposit_walks(pm, G, n):
         assert_density(sim.density(), O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
 
 
+@pytest.mark.parametrize("units", ["0", "1"])
+def test_deposit_with_and_without_units(pm, monkeypatch, units):
+    """A deposit plans units for its crowded rows only while recent deposits counted some; otherwise the row kernel walks
+    every row itself and is the deposit's only kernel beside the plan.  Either way is right for any set: a set with a dense
+    clump and the uniform golden set, each with the units forced off and forced on; and the switch itself -- a context
+    that starts with the units on, finds none on a uniform set, and goes on without them."""
+    monkeypatch.setenv("PM_DEPOSIT_UNITS", units)
+    n, G, L = 300_000, 64, 10000
+    rng = np.random.default_rng(12)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    pos[: n // 3] = (2500 + rng.normal(0, 60, (n // 3, 3))).astype(np.float32)
+    mass = (rng.random(n) + 0.5).astype(np.float32)
+    with pm.Simulation(G, L, pos, None, mass) as sim:
+        for _ in range(3):                              # (the counters of a deposit are zeroed by the one before)
+            sim.deposit()
+            assert_density(sim.density(), O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
+    monkeypatch.delenv("PM_DEPOSIT_UNITS")
+    upos = (rng.random((n, 3)) * L).astype(np.float32)
+    with pm.Simulation(G, L, upos, None, mass) as sim:
+        for _ in range(4):                              # on from the start, off once the count of none has come back
+            sim.deposit()
+            sim.synchronize()
+            assert_density(sim.density(), O.CIC(upos, G, L, mass), O.CIC_f64(upos, G, L, mass))
+        sim.set_particles(pos, None, mass)              # a new set: on again
+        for _ in range(3):
+            sim.deposit()
+            sim.synchronize()
+            assert_density(sim.density(), O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
+
+
 def test_deposit_is_bitwise_reproducible(pm):
     """Same input, fresh engines, clustered and sparse rows alike: identical bits every time."""
     n, G, L = 300_000, 64, 10000
