@@ -128,6 +128,8 @@ int whole_mesh(pm_ctx *c)
 // the float32 mesh `which` must hold the output of the stage before, or what pm_set_mesh put there
 int need_mesh(pm_ctx *c, int which, const char *what)
 {
+    // (a fused step computes the potential rows its own gather reads: whoever else wants the mesh gets the rest now)
+    if (which == PM_MESH_POTENTIAL && (c->mesh_valid & (1u << which)) && c->potential_partial) return pm_complete_potential(c);
     if (c->mesh_valid & (1u << which)) return PM_OK;
     return fail(c, PM_ESTATE, std::string("no ") + what + ": run the stage that writes it (or pm_set_mesh) first; a fused pm_step keeps neither the density nor the gradient meshes");
 }
@@ -200,6 +202,7 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->counters, 0, 2 * 8256 * sizeof(uint32_t), c->stream));
     TRY(dalloc(c, &c->row_unit, planes * G + 1));
     if (!c->slab && c->fft_custom) TRY(dalloc(c, &c->row_live, plane / 64 + 2));
+    if (!c->slab && c->fft_custom) TRY(dalloc(c, &c->row_need, plane / 64 + 2));
     TRY(dalloc(c, &c->unit_src, pm_max_units(cap)));
     TRY(dalloc(c, &c->unit_rows, pm_max_units(cap) * 4 * (size_t)G));
     TRY(dalloc(c, &c->light_rows, pm_heavy_row_entries(G, cap) * (size_t)G));
@@ -311,7 +314,7 @@ void pm_destroy(pm_ctx *c)
     for (int u = 0; u < 2; ++u) { hipFree(c->pf[u]); hipFree(c->pd[u]); hipFree(c->vf[u]); hipFree(c->vd[u]); }
     hipFree(c->frac); hipFree(c->elog);
     hipFree(c->key_in); hipFree(c->key_out); hipFree(c->src); hipFree(c->sort_tmp);
-    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src); hipFree(c->row_live);
+    hipFree(c->row_start); hipFree(c->heavy_rows); hipFree(c->counters); hipFree(c->unit_rows); hipFree(c->light_rows); hipFree(c->row_unit); hipFree(c->unit_src); hipFree(c->row_live); hipFree(c->row_need);
     if (c->slab && c->wmax != c->slabn) { hipFree(c->mesh_spec); hipFree(c->mesh_pot); }      // (else they alias spectrum / potential)
     hipFree(c->cuts);
     hipFree(c->density); hipFree(c->potential); hipFree(c->spectrum); hipFree(c->twiddle);
@@ -515,13 +518,20 @@ static int deposit_impl(pm_ctx *c, bool to_spectrum)
 int pm_deposit(pm_ctx *c) { return deposit_impl(c, false); }
 
 // have_z: the half spectrum already holds the z-transformed density rows (fused deposit)
-static int potential_impl(pm_ctx *c, bool have_z)
+// needed_rows (a fused step, right after its deposit): the last pass, inverse along z, is run for the rows that the step's
+// gather reads only (pm_ctx::row_need); the potential mesh is then partial until someone asks for all of it
+static int potential_impl(pm_ctx *c, bool have_z, bool needed_rows = false)
 {
     TRY(whole_mesh(c));
     if (!c) return PM_EINVAL;
     if (!have_z) TRY(need_mesh(c, PM_MESH_DENSITY, "density"));
     HIP_TRY(c, hipSetDevice(c->device));
     c->mesh_valid |= 1u << PM_MESH_POTENTIAL;
+#ifdef PM_POTENTIAL_WHOLE
+    needed_rows = false;
+#endif
+    needed_rows = needed_rows && have_z && c->fft_custom && c->rows_marked && !c->want_full_potential;
+    c->potential_partial = needed_rows;
     if (c->fft_custom && !(c->flags & PM_FLAG_TIMING)) {
         // The three column passes (along y, along x with the Green multiply, back along y) touch the same columns c:
         // they are run over one group of column tiles after the other, a group being small enough (200 MB) that
@@ -542,7 +552,7 @@ static int potential_impl(pm_ctx *c, bool have_z)
             HIP_TRY(c, pm_launch_col_fft_tiles(c, 0, t0, nt));
             HIP_TRY(c, pm_launch_col_fft_tiles(c, 1, t0, nt));
         }
-        HIP_TRY(c, pm_launch_row_fft(c, false));
+        HIP_TRY(c, pm_launch_row_fft(c, false, needed_rows));
         return PM_OK;
     }
     {
@@ -571,7 +581,7 @@ static int potential_impl(pm_ctx *c, bool have_z)
                 HIP_TRY(c, pm_launch_col_fft(c, 1));
             }
             kernel_timer k(c, PM_KERNEL_ROW_INV);
-            HIP_TRY(c, pm_launch_row_fft(c, false));
+            HIP_TRY(c, pm_launch_row_fft(c, false, needed_rows));
         } else {
             void *in[1] = {c->spectrum}, *out[1] = {c->potential};
             FFT_TRY(c, rocfft_execute(c->inv, in, out, c->info));
@@ -581,6 +591,17 @@ static int potential_impl(pm_ctx *c, bool have_z)
 }
 
 int pm_potential(pm_ctx *c) { return potential_impl(c, false); }
+
+// The rows of the potential mesh that the last fused step left out (potential_impl), from the half spectrum, which holds the
+// input of the inverse transform along z until the next potential is computed.  No allocation, nothing waited for.
+extern "C++" int pm_complete_potential(pm_ctx *c)
+{
+    if (!c->potential_partial) return PM_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, pm_launch_row_fft(c, false, false));
+    c->potential_partial = false;
+    return PM_OK;
+}
 
 int pm_set_softening(pm_ctx *c, double length)
 {
@@ -658,7 +679,7 @@ int pm_step(pm_ctx *c, double dt, int nsteps)
         // fused mode on the hand-written FFT path: the deposit leaves z-transformed rows, no density mesh
         const bool z_in_deposit = fused && c->fft_custom;
         TRY(deposit_impl(c, z_in_deposit));
-        TRY(potential_impl(c, z_in_deposit));
+        TRY(potential_impl(c, z_in_deposit, fused));
         if (!fused) TRY(pm_gradient(c));
         else c->mesh_valid &= ~((1u << PM_MESH_GX) | (1u << PM_MESH_GY) | (1u << PM_MESH_GZ));     // differenced on the fly
         TRY(gather_kick_drift(c, dt, fused));
@@ -695,7 +716,9 @@ int pm_run(pm_ctx *c, double dt, int nsteps, float *trajectory, int energy_every
     double *elog = c->elog;
     int rc = PM_OK;
     for (int s = 0; s < nsteps && rc == PM_OK; ++s) {
+        c->want_full_potential = energy_every > 0 && s % energy_every == 0;    // (the sample reads the mesh at the new positions)
         rc = pm_step(c, dt, 1);
+        c->want_full_potential = false;
         if (rc != PM_OK) break;
         if (trajectory && n) {
             const int b = s & 1;
@@ -814,6 +837,7 @@ int pm_set_mesh(pm_ctx *c, int which, const float *in)
     HIP_TRY(c, hipMemcpyAsync(p, in, (size_t)c->g.M * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->mesh_valid |= 1u << which;
+    if (which == PM_MESH_POTENTIAL) c->potential_partial = false;
     return PM_OK;
 }
 

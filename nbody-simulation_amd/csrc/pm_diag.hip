@@ -411,6 +411,7 @@ extern "C" int pm_energies_noalloc(pm_ctx *c, double *device_ke_pe)
         return fail(PM_ESTATE, "no float64 potential yet: step, or call pm_potential_f64 / pm_set_mesh_f64 first");
     if (!(c->flags & (PM_FLAG_NGP | PM_FLAG_F64)) && !(c->mesh_valid & (1u << PM_MESH_POTENTIAL)))
         return fail(PM_ESTATE, "no potential yet: step, or call pm_potential / pm_set_mesh(PM_MESH_POTENTIAL) first");
+    if (c->potential_partial && pm_complete_potential(c) != PM_OK) return PM_EHIP;      // (a kernel launch: no allocation, no wait)
     hipError_t e = hipSetDevice(c->device);
     double *partials = nullptr;
     if (e == hipSuccess) e = noalloc_scratch(c->device, &partials);

@@ -313,19 +313,25 @@ k_row_r2c(const float *__restrict__ in, float2 *__restrict__ out, int pitch, con
 
 template <int N>
 __global__ void __launch_bounds__(FFT_BLOCK)
-k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, const float2 *__restrict__ twiddle, int sb)
+k_row_c2r(const float2 *__restrict__ in, float *__restrict__ out, int pitch, const float2 *__restrict__ twiddle, int sb,
+          const unsigned long long *__restrict__ need)
 {
     constexpr int E = N / 128, M = N / 2;
     __shared__ float2 tw[N];
     __shared__ float2 bufs[FFT_BLOCK / 64][M + 4];
     const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
     float2 *buf = bufs[w];
-    for (int q = threadIdx.x; q < N; q += FFT_BLOCK) tw[q] = twiddle[q];
-    __syncthreads();
     // last planes first: the pass along y before this one ends with them, and the gather after it starts with the first
     const int64_t row0 = ((int64_t)(gridDim.x - 1 - blockIdx.x) * (FFT_BLOCK / 64) + w) * ROWS_PER_WAVE;
+    // need: a bit per row, set where the row will be read; the others are left as they are.  (One word per wave, asked for
+    // together with the twiddles: a wave is a short chain of waits and should not start with one more.)
+    static_assert(64 % ROWS_PER_WAVE == 0, "a wave's rows share a word of the marks");
+    const unsigned long long needed = need != nullptr ? need[row0 >> 6] : ~0ull;
+    for (int q = threadIdx.x; q < N; q += FFT_BLOCK) tw[q] = twiddle[q];
+    __syncthreads();
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
         const int64_t row = row0 + rr;
+        if (!((needed >> (row & 63)) & 1ull)) continue;
         const float2 *src = in + pm_spec_row(N, sb, (int)(row / N), (int)(row % N)) * pitch;
         float2 x[E], v[E];
 #pragma unroll
@@ -389,13 +395,14 @@ hipError_t launch_col_any(pm_ctx *c, int dir, const col_pass &p, int blocks)
 }
 
 // sb: the interleaving of `spec` (0 for the plane buffers of a slab)
-hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int64_t rows, int sb)
+hipError_t launch_rows(pm_ctx *c, bool forward, const float *real_in, float *real_out, float2 *spec, int64_t rows, int sb,
+                       const unsigned long long *need = nullptr)
 {
     const int blocks = (int)(rows / ((FFT_BLOCK / 64) * ROWS_PER_WAVE));
     return with_grid(c->g.G, [&](auto n) {
         constexpr int N = decltype(n)::value;
         if (forward) k_row_r2c<N><<<blocks, FFT_BLOCK, 0, c->stream>>>(real_in, spec, c->g.Ghp, c->twiddle, sb);
-        else k_row_c2r<N><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle, sb);
+        else k_row_c2r<N><<<blocks, FFT_BLOCK, 0, c->stream>>>(spec, real_out, c->g.Ghp, c->twiddle, sb, need);
         return hipGetLastError();
     });
 }
@@ -437,9 +444,10 @@ hipError_t pm_fft_upload_twiddles(pm_ctx *c)
 }
 
 // z axis: density (G,G,G) -> half spectrum (forward), half spectrum -> potential (inverse)
-hipError_t pm_launch_row_fft(pm_ctx *c, bool forward)
+hipError_t pm_launch_row_fft(pm_ctx *c, bool forward, bool needed_only)
 {
-    return launch_rows(c, forward, c->density, c->potential, c->spectrum, (int64_t)c->g.G * c->g.G, c->g.sb);
+    return launch_rows(c, forward, c->density, c->potential, c->spectrum, (int64_t)c->g.G * c->g.G, c->g.sb,
+                       !forward && needed_only ? c->row_need : nullptr);
 }
 
 static col_pass pass_for(pm_ctx *c, float2 *spec)

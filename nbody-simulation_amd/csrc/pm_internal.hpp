@@ -125,6 +125,13 @@ struct pm_ctx {
     uint32_t *row_unit = nullptr;       // per mesh row: first unit of a crowded row, or none
     unsigned long long *row_live = nullptr;     // whole meshes: a bit per density row, set where the deposit has something to add (k_plan_units)
     bool rows_marked = false;           // the last deposit left its empty rows unwritten and marked them in row_live instead
+    // whole meshes: a bit per POTENTIAL row, set where a particle of the last deposit reads the row in its gather (the rows of
+    // its cloud's corners and their neighbours along x and y).  A fused step runs the inverse transform along z for those
+    // rows only; potential_partial says that the others are stale, and whoever needs the whole mesh (pm_get_mesh, pm_gradient,
+    // the energies) has them transformed first (pm_complete_potential): the half spectrum still holds their input.
+    unsigned long long *row_need = nullptr;
+    bool potential_partial = false;
+    bool want_full_potential = false;   // pm_run: the step about to run is followed by an energy sample
     uint32_t *unit_src = nullptr;       // per unit: the mesh row it is a part of
     uint2 *heavy_rows = nullptr;        // density rows with a crowded source: (row, has a partial sum in light_rows)
     uint32_t *counters = nullptr;       // units handed out, density rows listed: two sets of 64 words that take turns
@@ -284,7 +291,9 @@ hipError_t pm_launch_append(pm_ctx *c, const pm_migrant *src, int64_t count);
 hipError_t pm_launch_set_ids(pm_ctx *c, const uint32_t *ids);
 hipError_t pm_launch_export_slab(pm_ctx *c, uint32_t *ids, float *pos, float *vel);
 hipError_t pm_launch_outbox_counts(pm_ctx *c, int64_t *device_counts);
-hipError_t pm_launch_row_fft(pm_ctx *c, bool forward);
+int pm_complete_potential(pm_ctx *c);
+// needed_only (inverse only): only the rows that row_need marks
+hipError_t pm_launch_row_fft(pm_ctx *c, bool forward, bool needed_only = false);
 // (rows_marked: the forward pass along y takes the rows that row_live marks empty as zeros, without reading them)
 hipError_t pm_launch_col_fft_tiles(pm_ctx *c, int dir, int tile0, int ntiles, bool rows_marked = false);
 int pm_fft_tiles(const pm_ctx *c);

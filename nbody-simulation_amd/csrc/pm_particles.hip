@@ -600,10 +600,37 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
 // there would have been.
 __global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32_t *__restrict__ row_unit, uint32_t *__restrict__ unit_src,
                              uint32_t *__restrict__ counters, unsigned long long *__restrict__ row_live, uint32_t G, bool plan,
-                             uint32_t *__restrict__ next_counters, volatile uint32_t *__restrict__ units_seen)
+                             uint32_t *__restrict__ next_counters, volatile uint32_t *__restrict__ units_seen,
+                             unsigned long long *__restrict__ row_need)
 {
     const uint32_t row = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t len = row < R ? rs[row + 1] - rs[row] : 0u;
+    if (row_need != nullptr) {
+        // row_need (with row_live): a bit per POTENTIAL row (a, b), set where the gather of some particle reads the row.  A
+        // particle of mesh row (i, j) takes the gradient at the corners (i .. i + 1, j .. j + 1) of its cloud (functions.py:
+        // 118-180, wrapped), which np.gradient (main.py:54) differences from the rows one to either side, one-sided at the
+        // faces: all of them among (i - 1 .. i + 2, j - 1 .. j + 2), wrapped.  So (a, b) is read if one of the sixteen mesh
+        // rows (a - 2 .. a + 1, b - 2 .. b + 1) holds a particle.
+        // (G is a multiple of 64 here: a wave holds 64 consecutive b of one a.  Per plane i the wave's lanes look up their
+        // own row and three of them the two rows before and the one after the wave's; the marks of b - 2 .. b + 1 are then
+        // shifts of one word.)
+        const uint32_t lane = (uint32_t)lane_id(), a = row / G, b0 = (row - a * G) & ~63u;
+        unsigned long long need = 0ull;
+        if (row < R) {
+#pragma unroll
+            for (uint32_t da = 0; da < 4; ++da) {
+                const uint32_t base = ((a + G + 1u - da) % G) * G;
+                const uint32_t q = base + b0 + lane;
+                const unsigned long long word = __ballot(rs[q + 1] != rs[q]);
+                // lanes 0, 1, 2: rows b0 - 2, b0 - 1, b0 + 64 (wrapped)
+                const uint32_t e = base + (lane == 2u ? (b0 + 64u) % G : (b0 + G - 2u + lane) % G);
+                const unsigned long long edge = __ballot(lane < 3u && rs[e + 1] != rs[e]);
+                const unsigned long long m2 = edge & 1ull, m1 = (edge >> 1) & 1ull, p1 = (edge >> 2) & 1ull;
+                need |= word | (word << 1) | m1 | (word << 2) | (m1 << 1) | m2 | (word >> 1) | (p1 << 63);
+            }
+        }
+        if (lane == 0 && row < R) row_need[row >> 6] = need;
+    }
     if (row_live != nullptr) {
         bool live = len != 0u;
         if (row < R && !live) {
@@ -639,12 +666,21 @@ __global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32
     __shared__ uint32_t last;
     __syncthreads();                                    // the workgroup's counts have been added
     if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(counters + COUNTER_PLANNED, 1u) == gridDim.x - 1u;
+        // (two levels -- atomics on one address go one at a time, a thousand of them take as long as the rest of this kernel
+        // five times over: the workgroups count themselves in up to 64 groups, on the lines that are the row kernel's turn
+        // counters when units are planned, and the last of each group counts the group)
+        const uint32_t per = (gridDim.x + 63u) / 64u, group = blockIdx.x / per, groups = (gridDim.x + per - 1u) / per;
+        const uint32_t members = (group + 1u) * per <= gridDim.x ? per : gridDim.x - group * per;
+        // (No fence: a fence of device scope writes back the L2, which holds what the reorder kernel has just written, and a
+        // thousand of those took 30 us.  None is needed: the only thing the last workgroup reads of the others is the unit
+        // count, which they add to with atomics of device scope whose results they have used -- so those are done -- before
+        // they come here, and which it reads with one.)
+        last = 0u;
+        if (atomicAdd(counters + COUNTER_TICKETS + 32u * group, 1u) == members - 1u)
+            last = atomicAdd(counters + COUNTER_PLANNED, 1u) == groups - 1u;
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();
     if (threadIdx.x == 0) *units_seen = __hip_atomic_load(counters + COUNTER_UNITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t q = threadIdx.x; q < COUNTER_WORDS; q += BLOCK) next_counters[q] = 0u;
 }
@@ -1371,7 +1407,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     // (a whole mesh whose rows leave as half-spectrum rows for the pass along y of this library: the empty rows are marked
     // instead of written)
     // (grid sizes whose pass along y has a thread read rows jl, jl + 64, ...: one word of the marks per row read)
-    const bool mark_rows = (NFFT == 512 || NFFT == 1024) && !c->slab && c->row_live != nullptr;
+    const bool mark_rows = (NFFT == 512 || NFFT == 1024) && !c->slab && c->row_live != nullptr && c->row_need != nullptr;
     c->rows_marked = mark_rows;
     // Crowded rows are planned as units only while recent deposits had some (the count comes back to the host without anyone
     // waiting for it, so it is a step or two old): a set without them -- a uniform one -- then runs two kernels instead of
@@ -1381,7 +1417,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     const char *forced = std::getenv("PM_DEPOSIT_UNITS");
     const bool planned = forced ? forced[0] != '0' : *c->units_seen != 0;
     k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, counters, mark_rows ? c->row_live : nullptr, (uint32_t)G,
-                                                       planned, next_counters, c->units_seen_dev);
+                                                       planned, next_counters, c->units_seen_dev, mark_rows ? c->row_need : nullptr);
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
     const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);

@@ -159,11 +159,14 @@ def test_fused_step_512(pm):
     for fused in (False, True):
         with pm.Simulation(G, L, pos, vel, mass, fused_gradient=fused) as sim:
             sim.step(dt, 3)
-            out.append((sim.positions(), sim.velocities()))
+            out.append((sim.positions(), sim.velocities(), sim.energies(), sim.potential()))
     dx = np.abs(out[0][0].astype(np.float64) - out[1][0])
     assert np.minimum(dx, L - dx).max() <= 1e-6 * L
     assert np.abs(out[0][1] - out[1][1]).max() <= 1e-6 * np.abs(out[0][1]).max()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])     # the same bits, in fact
+    # The fused step transforms only the potential rows that its gather reads (most of this mesh is empty); asked for, the
+    # energies and the mesh are those of the whole potential all the same.
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3])
 
 
 def test_cell_order_over_steps(pm, golden, binning_ways):
