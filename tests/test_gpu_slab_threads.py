@@ -14,6 +14,17 @@ pytestmark = pytest.mark.gpu
 _create = threading.Lock()
 
 
+def free_device_memory():
+    """Bytes of device memory that are free once what earlier tests left behind (contexts awaiting collection, blocks that
+    torch's allocator keeps) has been given back."""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return torch.cuda.mem_get_info()[0]
+
+
 def run_threads(world, build, steps, dt, chunks=None, keep="all", info=None, **sim_args):
     """build(rank) -> (G, L, pos, vel, mass, ids, capacity); returns per rank [(ids, pos, vel) after each step] (keep =
     "last": after the last step only).  sim_args go to SlabSimulation; info(rank, sim) -> anything is called at the end and
@@ -129,7 +140,7 @@ def test_mesh_of_the_eight_gpu_configuration():
     x pass on the transposed spectrum, both transposes in two groups of planes, halos, migration of the 2^15 particles
     at the top of every slab) with 2^26 particles on a lattice, against the closed form."""
     import torch
-    free, _ = torch.cuda.mem_get_info()
+    free = free_device_memory()
     if free < 235e9:
         pytest.skip(f"needs about 200 GB of device memory for the eight slabs, {free / 1e9:.0f} GB are free")
     lattice_run(2048, 8, 128, 16, 2)
@@ -238,7 +249,7 @@ def test_disk_of_the_clustered_configuration_in_eight_windows():
     import torch
     import pm
     from pm.distributed import balanced_cuts, generated_plane_counts, owner_by_cuts
-    free, _ = torch.cuda.mem_get_info()
+    free = free_device_memory()
     if free < 150e9:
         pytest.skip(f"needs about 120 GB of device memory, {free / 1e9:.0f} GB are free")
     n, G, L, dt, world, K = 67_108_864, 1024, 10000, 0.005, 8, 2
@@ -322,7 +333,7 @@ def test_uniform_set_of_the_eight_gpu_configuration_on_its_mesh():
     import torch
     from oracle import pm_oracle as O
     from pm.distributed import slab_of
-    free, _ = torch.cuda.mem_get_info()
+    free = free_device_memory()
     if free < 235e9:
         pytest.skip(f"needs about 200 GB of device memory for the eight slabs, {free / 1e9:.0f} GB are free")
     n, G, L, dt, world = 1 << 26, 2048, 10000, 0.005, 8
