@@ -169,7 +169,10 @@ int pm_get_particles(pm_ctx *ctx, void *pos, int *pos_dtype, void *vel, int *vel
 int pm_get_forces(pm_ctx *ctx, float *forces /* (n,3) */);
 /* A mesh can be read (and the stage that consumes it can run) once the stage that writes it has run or pm_set_mesh
  * has put it there; otherwise PM_ESTATE.  pm_step with PM_FLAG_FUSED_GRADIENT writes no gradient meshes and, on the
- * hand-written transforms, no density mesh: after it only PM_MESH_POTENTIAL can be read. */
+ * hand-written transforms, no density mesh: after it only PM_MESH_POTENTIAL can be read.  (Such a step transforms back
+ * only the potential rows that its own gather reads; pm_get_mesh, pm_gradient and the energy calls have the other rows
+ * transformed before they read the mesh -- one more kernel on the context's stream, no allocation -- so what they see is
+ * the whole potential of functions.py:89.) */
 int pm_get_mesh(pm_ctx *ctx, int which, float *out /* G*G*G */);
 /* Upload a mesh, so that one stage can be run on the caller's input
  * (granular mode: compute_potential(density), np.gradient(potential),

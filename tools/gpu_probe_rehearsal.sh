@@ -1,5 +1,5 @@
 #!/bin/bash
-# Two ranks on the one GPU under the driver's launcher: the replica bench with its slab probe in child processes,
+# Two ranks on the one GPU under the driver's launcher (bench.py --gpus 2 is the slab run),
 # first with host-staged exchanges (gloo: the whole child path runs), then with nccl (two ranks on one GPU: RCCL refuses,
 # and the line must carry that error rather than a timeout).
 mkdir -p gpurun_out
