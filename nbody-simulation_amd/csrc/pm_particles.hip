@@ -1495,9 +1495,9 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     }
     if (beside && (e = hipStreamWaitEvent(c->stream, c->ev_join, 0)) != hipSuccess) return e;
     if (planned)
-    k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
-                                                                                        c->light_rows, c->density, c->spectrum, c->twiddle, c->g,
-                                                                                        next_counters, c->units_seen_dev);
+        k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
+                                                                                            c->light_rows, c->density, c->spectrum, c->twiddle, c->g,
+                                                                                            next_counters, c->units_seen_dev);
     return hipGetLastError();
 }
 
