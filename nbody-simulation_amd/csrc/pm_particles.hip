@@ -48,14 +48,15 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK
 // consecutive particles are fetched into one L2 only.  -3 % for that kernel on the clustered set, -1.5 % on the uniform
 // one; one contiguous eighth of the particles per XCD is 30 % slower.
 template <int C>
-__device__ __forceinline__ uint32_t xcd_block()
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t blocks)
 {
-    if (C == 0) return blockIdx.x;
-    const uint32_t b = blockIdx.x, span = 8u * (uint32_t)(C ? C : 1), base = b / span * span;
-    if (base + span > gridDim.x) return b;           // the last, partial run keeps its order
+    if (C == 0) return b;
+    const uint32_t span = 8u * (uint32_t)(C ? C : 1), base = b / span * span;
+    if (base + span > blocks) return b;              // the last, partial run keeps its order
     const uint32_t o = b - base;
     return base + (o & 7u) * (uint32_t)C + (o >> 3);
 }
+template <int C> __device__ __forceinline__ uint32_t xcd_block() { return xcd_block<C>(blockIdx.x, gridDim.x); }
 #ifndef PM_GATHER_XCD
 #define PM_GATHER_XCD 16
 #endif
@@ -171,58 +172,37 @@ __global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__res
 #ifndef PM_REORDER_XCD
 #define PM_REORDER_XCD 64
 #endif
-// rs != nullptr: the kernel also writes row_start (see k_row_start) from the sorted keys: the thread of slot r, whose key
-// lies in mesh row b while the key before it lies in row a < b, writes rs[a + 1 .. b] = r (the thread of slot 0: rs[0 .. b]
-// = 0, the thread of the last slot also rs[b + 1 .. R] = n).  Stretches of more than a few rows -- empty regions of the
-// mesh -- are written by the whole wave.
+// rs_blocks > 0: the first rs_blocks workgroups of the launch are those of k_row_start (a row per thread, one bisection each),
+// which like the reorder needs the sorted keys only: their chains of dependent loads run beside the reorder's streams
+// instead of after them, in a launch of their own (16.7 M particles: 16 us and a launch less; 1M / 128^3: 5 us).
+__device__ __forceinline__ void row_start_of(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs, uint32_t row);
+
 template <typename TP>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
                           pm_frac *__restrict__ F, const uint32_t *__restrict__ src, int64_t n, pm_geom g,
-                          const uint32_t *__restrict__ key, uint32_t R, uint32_t *__restrict__ rs)
+                          const uint32_t *__restrict__ key, uint32_t R, uint32_t *__restrict__ rs, uint32_t rs_blocks)
 {
-    uint32_t blk = blockIdx.x;
+    if (blockIdx.x < rs_blocks) {
+        row_start_of(key, n, (uint32_t)g.G, R, rs, blockIdx.x * BLOCK + threadIdx.x);
+        return;
+    }
+    uint32_t blk = blockIdx.x - rs_blocks;
+    const uint32_t blocks = gridDim.x - rs_blocks;
     if constexpr (PM_REORDER_XCD < 0) {                 // every XCD one contiguous eighth of the slots
-        const uint32_t per = gridDim.x / 8u;
+        const uint32_t per = blocks / 8u;
         if (blk < per * 8u) blk = (blk & 7u) * per + (blk >> 3);
-    } else blk = xcd_block<PM_REORDER_XCD>();
+    } else blk = xcd_block<PM_REORDER_XCD>(blk, blocks);
     int64_t r = (int64_t)blk * BLOCK + threadIdx.x;
-    const bool live = r < n;
-    if (rs == nullptr && !live) return;
-    if (live) {
-        const pm_prec<TP> rec = Pin[src[r]];
-        Pout[r] = rec;
-        F[r] = pmcell::fraction_record(rec, g);
-    }
-    if (rs == nullptr) return;
-    // (every lane of the wave stays for the stretches the wave writes together)
-    const uint32_t G = (uint32_t)g.G, at = (uint32_t)r;
-    uint32_t own = 0, first = 0, count = 0, tail = 0;   // rows first .. first + count - 1 take r; the `tail` rows after row `own` take n
-    if (live) {
-        own = key[r] / G;
-        first = r == 0 ? 0u : key[r - 1] / G + 1u;
-        count = own + 1u - first;
-        if (r == n - 1) tail = R - own;
-    }
-    if (count <= 4u) {
-        for (uint32_t q = 0; q < count; ++q) rs[first + q] = at;
-        count = 0;
-    }
-    unsigned long long m = __ballot(count != 0u || tail != 0u);
-    const uint32_t lane = (uint32_t)lane_id();
-    while (m) {
-        const int l = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const uint32_t f = __shfl(first, l), c = __shfl(count, l), v = __shfl(at, l), after = __shfl(own, l) + 1u, t = __shfl(tail, l);
-        for (uint32_t q = lane; q < c; q += 64u) rs[f + q] = v;
-        for (uint32_t q = lane; q < t; q += 64u) rs[after + q] = (uint32_t)n;
-    }
+    if (r >= n) return;
+    const pm_prec<TP> rec = Pin[src[r]];
+    Pout[r] = rec;
+    F[r] = pmcell::fraction_record(rec, g);
 }
 
 // row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
 // [0, G*G]: one bisection of the sorted keys per row.
-__global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs)
+__device__ __forceinline__ void row_start_of(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs, uint32_t row)
 {
-    uint32_t row = blockIdx.x * BLOCK + threadIdx.x;
     if (row > R) return;
     const uint64_t target = (uint64_t)row * G;          // first key of the row
     int64_t lo = 0, hi = n;                             // first index in [lo, hi] with key >= target
@@ -231,6 +211,10 @@ __global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_
         if ((uint64_t)key[mid] < target) lo = mid + 1; else hi = mid;
     }
     rs[row] = (uint32_t)lo;
+}
+__global__ void k_row_start(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs)
+{
+    row_start_of(key, n, G, R, rs, blockIdx.x * BLOCK + threadIdx.x);
 }
 
 // ---- CIC deposit ---------------------------------------------------------------------------
@@ -1348,30 +1332,22 @@ static hipError_t settle_velocities(pm_ctx *c)
     return hipGetLastError();
 }
 
-// row_starts: row_start is brought up to date as well (by the same kernel or by pm_launch_row_start)
-#ifndef PM_ROW_STARTS_FUSED_MAX
-#define PM_ROW_STARTS_FUSED_MAX (1 << 22)
-#endif
+// row_starts: row_start is brought up to date as well (k_row_start's workgroups ride along at the front of the launch)
 hipError_t pm_launch_reorder(pm_ctx *c, bool row_starts)
 {
     int64_t n = c->n;
     if (n == 0) return row_starts ? pm_launch_row_start(c) : hipSuccess;
     int u = c->cur, w = 1 - u;
     pm_timer timed(c, PM_NSTAGES + PM_KERNEL_REORDER);
-    // (with the row starts: rows of the owned planes, as pm_launch_row_start)
-    const uint32_t R = (uint32_t)c->g.Gs * (uint32_t)c->g.G;
-    // Up to a few million particles the row starts come out of the reorder kernel (1M particles on 128^3: one launch of 7 us
-    // less in a step of 0.19 ms); for more a kernel of their own is faster than what they cost the reorder, which is
-    // at its memory bandwidth (16.7M particles: 16 us against 22).
-    const bool fused = row_starts && n <= PM_ROW_STARTS_FUSED_MAX;
-    uint32_t *rs = fused ? c->row_start : nullptr;
-    if (c->pos_f64) k_reorder<double><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g, c->key_out, R, rs);
-    else k_reorder<float><<<grid_for(n), BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g, c->key_out, R, rs);
+    const uint32_t R = (uint32_t)c->g.Gs * (uint32_t)c->g.G;        // mesh rows of the owned planes, as pm_launch_row_start
+    const uint32_t rs_blocks = row_starts ? (uint32_t)grid_for((int64_t)R + 1).x : 0u;
+    dim3 grid = grid_for(n);
+    grid.x += rs_blocks;
+    if (c->pos_f64) k_reorder<double><<<grid, BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g, c->key_out, R, c->row_start, rs_blocks);
+    else k_reorder<float><<<grid, BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g, c->key_out, R, c->row_start, rs_blocks);
     c->cur = w;
     c->v_stale = true;
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess && row_starts && !fused) e = pm_launch_row_start(c);
-    return e;
+    return hipGetLastError();
 }
 
 hipError_t pm_settle_velocities(pm_ctx *c) { return settle_velocities(c); }
