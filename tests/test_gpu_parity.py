@@ -167,6 +167,19 @@ def test_fused_step_512(pm):
     # The fused step transforms only the potential rows that its gather reads (most of this mesh is empty); asked for, the
     # energies and the mesh are those of the whole potential all the same.
     assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3])
+    # The main loop in one call samples the energies after steps 0 and 2: those steps transform every row at once, step 1 only
+    # the rows its gather reads.  Step by step with the energies asked for afterwards (the rest of the rows on demand) gives
+    # the same numbers and the same particles.
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+        traj, energies = sim.run(3, dt, trajectory=True, energy_every=2)
+        assert np.array_equal(traj[2], out[1][0]) and np.array_equal(sim.velocities(), out[1][1])
+    with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+        by_hand = []
+        for s in range(3):
+            sim.step(dt)
+            if s % 2 == 0:
+                by_hand.append(sim.energies())
+    assert [tuple(e[:2]) for e in energies] == by_hand and by_hand[1] == out[1][2]
 
 
 def test_cell_order_over_steps(pm, golden, binning_ways):
