@@ -176,8 +176,8 @@ static int create_impl(pm_ctx *c)
     HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    HIP_TRY(c, hipHostMalloc((void **)&c->units_seen, sizeof(uint32_t), hipHostMallocDefault));
-    *c->units_seen = 1;
+    HIP_TRY(c, hipHostMalloc((void **)&c->units_seen, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    for (int k = 0; k < 4; ++k) c->units_seen[k] = 0ull;
     HIP_TRY(c, hipHostGetDevicePointer((void **)&c->units_seen_dev, (void *)c->units_seen, 0));
     {
         HIP_TRY(c, hipHostMalloc((void **)&c->movers_seen, sizeof(uint32_t), hipHostMallocDefault));
@@ -410,7 +410,7 @@ int pm_set_particles(pm_ctx *c, const void *pos, int pos_dtype, const void *vel,
         HIP_TRY(c, pm_launch_pack(c, nullptr, nullptr, vel ? st : nullptr));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (c->units_seen) *c->units_seen = 1;              // a new set: crowded rows are planned for until a deposit has counted none
+    c->deposits_of_set = 0;                             // a new set: crowded rows are planned for until a deposit has counted none
     return PM_OK;
 }
 
@@ -449,7 +449,7 @@ int pm_generate(pm_ctx *c, int kind, int64_t n, uint64_t seed, const double *par
         c->n = n;
         HIP_TRY(c, pm_launch_generate(c, kind, n, seed, params));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->units_seen) *c->units_seen = 1;
+        c->deposits_of_set = 0;
         return PM_OK;
     }
     // a slab: every rank draws all n numbers and keeps the particles of its window, in the order of their numbers --

@@ -79,7 +79,14 @@ struct pm_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;         // a second stream: the units of crowded rows are summed beside the ordinary rows
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    volatile uint32_t *units_seen = nullptr;    // pinned host word: how many units a recent deposit planned (copied back without waiting)
+    // Four pinned host words that take turns: deposit number d (counted over the life of the context) writes d + 1 and how many
+    // units it planned, or would have planned, to word d % 4 -- one 8-byte store by its last kernel -- and deposit d + 2 reads
+    // that word, waiting for the number if it is not there yet (it is: that deposit finished a step ago), and plans units or
+    // not by the count.  The same deposit of the same run therefore always decides the same way, whatever the host's lead
+    // over the device: which of the two ways a deposit sums a crowded row shows in the last bits.
+    volatile unsigned long long *units_seen = nullptr;
+    uint64_t deposits = 0;                      // deposits of this context so far
+    uint64_t deposits_of_set = 0;               // ... since the particle set was given (its first two plan units)
     bool own_stream = true;     // false after pm_set_stream: the caller's stream, which orders this context's work with the caller's
 
     // Particle state, double-buffered: `cur` is the live set, 1-cur the target of the next
@@ -136,7 +143,7 @@ struct pm_ctx {
     uint2 *heavy_rows = nullptr;        // density rows with a crowded source: (row, has a partial sum in light_rows)
     uint32_t *counters = nullptr;       // units handed out, density rows listed: two sets of 64 words that take turns
     int counter_set = 0;                // the set the next deposit uses (zeroed by the deposit before it)
-    volatile uint32_t *units_seen_dev = nullptr;    // units_seen as the device addresses it
+    volatile unsigned long long *units_seen_dev = nullptr;    // units_seen (four words) as the device addresses it
     double *unit_rows = nullptr;        // four rows of G doubles per unit
     double *light_rows = nullptr;       // one row of G doubles per listed density row
 

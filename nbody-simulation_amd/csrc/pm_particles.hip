@@ -9,6 +9,7 @@
 #include "pm_fft_dev.hpp"
 
 #include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <type_traits>
 #include "pm_cell_dev.hpp"
@@ -584,7 +585,7 @@ __device__ __forceinline__ void emit_empty_row(float *__restrict__ density, floa
 // there would have been.
 __global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32_t *__restrict__ row_unit, uint32_t *__restrict__ unit_src,
                              uint32_t *__restrict__ counters, unsigned long long *__restrict__ row_live, uint32_t G, bool plan,
-                             uint32_t *__restrict__ next_counters, volatile uint32_t *__restrict__ units_seen,
+                             uint32_t *__restrict__ next_counters, volatile unsigned long long *__restrict__ units_seen, uint32_t turn,
                              unsigned long long *__restrict__ row_need)
 {
     const uint32_t row = blockIdx.x * BLOCK + threadIdx.x;
@@ -665,7 +666,8 @@ __global__ void k_plan_units(const uint32_t *__restrict__ rs, uint32_t R, uint32
     }
     __syncthreads();
     if (!last) return;
-    if (threadIdx.x == 0) *units_seen = __hip_atomic_load(counters + COUNTER_UNITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0)
+        *units_seen = ((unsigned long long)turn << 32) | __hip_atomic_load(counters + COUNTER_UNITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t q = threadIdx.x; q < COUNTER_WORDS; q += BLOCK) next_counters[q] = 0u;
 }
 
@@ -901,7 +903,7 @@ __global__ void __launch_bounds__(SUM_BLOCK)
 k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_unit, const uint2 *__restrict__ heavy_rows,
             const uint32_t *__restrict__ counters, const double *__restrict__ unit_rows, const double *__restrict__ light_rows,
             float *__restrict__ density, float2 *__restrict__ spectrum, const float2 *__restrict__ twiddle, pm_geom g,
-            uint32_t *__restrict__ next_counters, volatile uint32_t *__restrict__ units_seen)
+            uint32_t *__restrict__ next_counters, volatile unsigned long long *__restrict__ units_seen, uint32_t turn)
 {
     extern __shared__ double lds_rows[];                // one row of G doubles, then the NFFT twiddles
     const int G = g.G;
@@ -913,7 +915,7 @@ k_sum_units(const uint32_t *__restrict__ rs, const uint32_t *__restrict__ row_un
     // start at zero, and the host learns how many units this one had (a word of page-locked host memory)
     if (blockIdx.x == 0) {
         for (uint32_t q = threadIdx.x; q < COUNTER_WORDS; q += SUM_BLOCK) next_counters[q] = 0u;
-        if (threadIdx.x == 0) *units_seen = counters[COUNTER_UNITS];
+        if (threadIdx.x == 0) *units_seen = ((unsigned long long)turn << 32) | counters[COUNTER_UNITS];
     }
     const uint32_t entries = counters[COUNTER_ROWS];
     for (uint32_t e = blockIdx.x; e < entries; e += gridDim.x) {
@@ -1385,15 +1387,30 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     // (grid sizes whose pass along y has a thread read rows jl, jl + 64, ...: one word of the marks per row read)
     const bool mark_rows = (NFFT == 512 || NFFT == 1024) && !c->slab && c->row_live != nullptr && c->row_need != nullptr;
     c->rows_marked = mark_rows;
-    // Crowded rows are planned as units only while recent deposits had some (the count comes back to the host without anyone
-    // waiting for it, so it is a step or two old): a set without them -- a uniform one -- then runs two kernels instead of
-    // four.  Should crowded rows appear, the row kernel walks them itself, slowly but with the same sums, and the count
+    // Crowded rows are planned as units only while the deposit before the last had some (pm_ctx::units_seen): a set without
+    // them -- a uniform one -- then runs two kernels instead of four.  Should crowded rows appear, the row kernel walks them itself, slowly but with the same sums, and the count
     // that comes back switches the units on for the deposits that follow (a new particle set starts with them on).
     // (PM_DEPOSIT_UNITS in the environment, read at every deposit: "0" never plans units, anything else always -- tests)
     const char *forced = std::getenv("PM_DEPOSIT_UNITS");
-    const bool planned = forced ? forced[0] != '0' : *c->units_seen != 0;
+    const uint64_t turn = c->deposits++;
+    volatile unsigned long long *seen_dev = c->units_seen_dev + (turn & 3u);
+    bool planned = true;                                // (the first two deposits of a particle set)
+    if (c->deposits_of_set++ >= 2) {
+        // the word of the deposit before the last: there since a step ago (a host that is further ahead of the device than
+        // that waits here, first politely, then for the stream)
+        volatile unsigned long long *word = c->units_seen + ((turn - 2) & 3u);
+        const unsigned long long want = (turn - 2 + 1) & 0xffffffffull;
+        unsigned long long v = *word;
+        for (int spin = 0; (v >> 32) != want && spin < (1 << 16); ++spin) { std::this_thread::yield(); v = *word; }
+        if ((v >> 32) != want) {
+            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+            v = *word;
+        }
+        planned = (v >> 32) != want || (uint32_t)v != 0u;
+    }
+    if (forced) planned = forced[0] != '0';
     k_plan_units<<<grid_for(Rs), BLOCK, 0, c->stream>>>(c->row_start, Rs, c->row_unit, c->unit_src, counters, mark_rows ? c->row_live : nullptr, (uint32_t)G,
-                                                       planned, next_counters, c->units_seen_dev, mark_rows ? c->row_need : nullptr);
+                                                       planned, next_counters, seen_dev, (uint32_t)(turn + 1), mark_rows ? c->row_need : nullptr);
     const size_t tw_bytes = (size_t)NFFT * sizeof(float2);
     const size_t lds_rows = (size_t)(BLOCK / 64) * G * sizeof(double);
     const size_t lds_units = (size_t)(UNIT_BLOCK / 64) * 4 * G * sizeof(double);
@@ -1473,7 +1490,7 @@ static hipError_t deposit_dispatch(pm_ctx *c)
     if (planned)
         k_sum_units<NFFT><<<2048, SUM_BLOCK, (size_t)G * sizeof(double) + tw_bytes, c->stream>>>(c->row_start, c->row_unit, c->heavy_rows, counters, c->unit_rows,
                                                                                             c->light_rows, c->density, c->spectrum, c->twiddle, c->g,
-                                                                                            next_counters, c->units_seen_dev);
+                                                                                            next_counters, seen_dev, (uint32_t)(turn + 1));
     return hipGetLastError();
 }
 

@@ -619,6 +619,36 @@ def test_deposit_with_and_without_units(pm, monkeypatch, units):
             assert_density(sim.density(), O.CIC(pos, G, L, mass), O.CIC_f64(pos, G, L, mass))
 
 
+def test_steps_repeat_bit_for_bit_while_crowded_rows_appear(pm):
+    """A set that starts spread out (no crowded row: after two deposits the units are off) and falls into a clump within a
+    few steps (crowded rows: the row kernel walks them itself, then the units come on).  Which deposit goes which way is
+    decided by the count of the deposit before the last, never by how far the host happens to be ahead of the device: two
+    runs give the same bits at every step, hurried or not."""
+    n, G, L, dt = 300_000, 64, 10000.0, 0.005
+    rng = np.random.default_rng(21)
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    target = (5000 + rng.normal(0, 30, (n, 3))).astype(np.float32)
+    vel = ((target - pos) / (8 * dt)).astype(np.float32)               # there after eight steps: crowded rows from the seventh on
+    mass = np.full(n, 1e-9, np.float32)                                 # (no force worth the name: they arrive)
+    runs = []
+    for hurried in (True, False):
+        with pm.Simulation(G, L, pos, vel, mass, fused_gradient=True) as sim:
+            states = []
+            for s in range(10):
+                sim.step(dt)
+                if not hurried:
+                    sim.synchronize()
+                if hurried and s < 9:
+                    continue
+                states.append(sim.positions())
+            sim.deposit()
+            runs.append((states, sim.density()))
+    assert np.array_equal(runs[0][0][-1], runs[1][0][-1]) and np.array_equal(runs[0][1], runs[1][1])
+    x = runs[1][0][-1].astype(np.float64)
+    assert np.abs(x - 5000).max() < 2000 and len(runs[1][0]) == 10     # the clump formed; every step of the slow run was read
+    assert_density(runs[1][1], O.CIC(runs[1][0][-1], G, int(L), mass), O.CIC_f64(runs[1][0][-1], G, int(L), mass))
+
+
 def test_deposit_is_bitwise_reproducible(pm):
     """Same input, fresh engines, clustered and sparse rows alike: identical bits every time."""
     n, G, L = 300_000, 64, 10000
