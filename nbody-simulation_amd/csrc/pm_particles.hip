@@ -1048,7 +1048,24 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     // (Measured and not kept: wave w of the workgroup taking the w-th sixteen of each of the workgroup's four runs of 64
     // slots -- on a uniform set a quarter of the extent of four neighbouring mesh rows, which share their potential rows,
     // instead of one row from end to end: fewer lines per wave, but 0.62 ms against 0.59, and 3 % lost on a clustered set.)
+#ifdef PM_GATHER_BLOCKED
+    // (Tuning build: what a cell key blocked in (i, j) would do for this kernel on a UNIFORM set, without changing the key.
+    // There a workgroup's 256 slots are about four consecutive mesh rows and a plane is n / G / 256 workgroups, so taking the
+    // workgroups of B x B neighbouring (plane, position in plane) places one after the other puts the same neighbouring rows
+    // under neighbouring workgroups as that key would.)
+    uint32_t wg = blockIdx.x;
+    {
+        constexpr uint32_t B = PM_GATHER_BLOCKED;
+        const uint32_t per_plane = (uint32_t)(n / g.G / BLOCK), planes = (uint32_t)g.G;
+        if (per_plane % B == 0 && planes % B == 0 && wg < per_plane * planes) {
+            const uint32_t t = wg / (B * B), o = wg % (B * B), gi = t / (per_plane / B), gj = t % (per_plane / B);
+            wg = (gi * B + o / B) * per_plane + gj * B + o % B;
+        }
+    }
+    int64_t r = (int64_t)wg * BLOCK + threadIdx.x;
+#else
     int64_t r = (int64_t)xcd_block<PM_GATHER_XCD>() * BLOCK + threadIdx.x;
+#endif
     if (r >= n) return;
     const int G = g.G;
     const pm_prec<TP> p = Pin[r];
