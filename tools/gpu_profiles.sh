@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything under profiles/r03_* in one call on the GPU box: kernel traces (headline, uniform, disk-1024, 1M / 128^3), the
+# Everything under profiles/<tag>_* in one call on the GPU box (reduced afterwards by tools/pmc_traffic.py <tag>): kernel traces (headline, uniform, disk-1024, 1M / 128^3), the
 # FETCH_SIZE / WRITE_SIZE passes (headline and uniform set), the SQ counter passes of the particle kernels and the transforms.
 set -e
 bash tools/make_profiles.sh
