@@ -192,7 +192,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="two_galaxy", choices=["two_galaxy", "uniform", "disk"])
     ap.add_argument("--n", "--particles", dest="n", type=int, default=16_777_216)
     ap.add_argument("--grid", type=int, default=512)
