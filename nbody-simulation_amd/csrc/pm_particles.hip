@@ -58,6 +58,33 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t blocks)
     return base + (o & 7u) * (uint32_t)C + (o >> 3);
 }
 template <int C> __device__ __forceinline__ uint32_t xcd_block() { return xcd_block<C>(blockIdx.x, gridDim.x); }
+
+// Stores and loads of data that is written or read once, front to back, by kernels whose other accesses -- records fetched
+// through the permutation, rows of the potential -- are the ones worth keeping in the L2: marked non-temporal (the reorder
+// pass's sorted records and fraction records, the gather's records in and out and its keys; the sort's passes read their
+// input the same way).  Headline step 1.921 -> 1.897 ms; the same hint on the loads of the column passes or of the inverse
+// row pass costs more elsewhere than it gains there (1.95 and 1.90 ms), on the units' particle loads it changes nothing,
+// and on the scattered stores of the sort's passes, which the L2 puts together into lines, it costs 125 us.
+// Only for sets that do not fit the caches anyway (more than PM_STREAM_MIN particles): on 1M particles, where one kernel's
+// output is the next one's cache hit, the same hints cost a step of 0.178 ms 6 us.
+#ifndef PM_STREAM_MIN
+#define PM_STREAM_MIN (1 << 22)
+#endif
+typedef uint32_t pm_u4 __attribute__((ext_vector_type(4)));
+// (STREAM is a template argument of the kernels, chosen by the launcher: as a run-time condition the two stores are merged
+// into one by the compiler and the hint is lost)
+template <bool STREAM, typename T> __device__ __forceinline__ void stream_store(T *p, const T &v)
+{
+    if constexpr (STREAM && sizeof(T) == 16) __builtin_nontemporal_store(*(const pm_u4 *)&v, (pm_u4 *)p);
+    else if constexpr (STREAM && sizeof(T) == 4) __builtin_nontemporal_store(*(const uint32_t *)&v, (uint32_t *)p);
+    else *p = v;
+}
+template <bool STREAM, typename T> __device__ __forceinline__ T stream_load(const T *p)
+{
+    if constexpr (STREAM && sizeof(T) == 16) { const pm_u4 v = __builtin_nontemporal_load((const pm_u4 *)p); return *(const T *)&v; }
+    else if constexpr (STREAM && sizeof(T) == 4) { const uint32_t v = __builtin_nontemporal_load((const uint32_t *)p); return *(const T *)&v; }
+    else return *p;
+}
 #ifndef PM_GATHER_XCD
 #define PM_GATHER_XCD 16
 #endif
@@ -178,7 +205,7 @@ __global__ void k_move_v(const pm_vrec<TV> *__restrict__ Vin, pm_vrec<TV> *__res
 // instead of after them, in a launch of their own (16.7 M particles: 16 us and a launch less; 1M / 128^3: 5 us).
 __device__ __forceinline__ void row_start_of(const uint32_t *__restrict__ key, int64_t n, uint32_t G, uint32_t R, uint32_t *__restrict__ rs, uint32_t row);
 
-template <typename TP>
+template <typename TP, bool STREAM>
 __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__restrict__ Pout,
                           pm_frac *__restrict__ F, const uint32_t *__restrict__ src, int64_t n, pm_geom g,
                           const uint32_t *__restrict__ key, uint32_t R, uint32_t *__restrict__ rs, uint32_t rs_blocks)
@@ -195,9 +222,9 @@ __global__ void k_reorder(const pm_prec<TP> *__restrict__ Pin, pm_prec<TP> *__re
     } else blk = xcd_block<PM_REORDER_XCD>(blk, blocks);
     int64_t r = (int64_t)blk * BLOCK + threadIdx.x;
     if (r >= n) return;
-    const pm_prec<TP> rec = Pin[src[r]];
-    Pout[r] = rec;
-    F[r] = pmcell::fraction_record(rec, g);
+    const pm_prec<TP> rec = Pin[stream_load<STREAM>(src + r)];
+    stream_store<STREAM>(Pout + r, rec);
+    stream_store<STREAM>(F + r, pmcell::fraction_record(rec, g));
 }
 
 // row_start[row] = number of particles whose mesh row (key / G = i*G + j) is < row, for row in
@@ -1037,7 +1064,7 @@ __device__ __forceinline__ void put_in_outbox(const outbox_t &ob, bool leaves, i
 // MAPPED: the velocity record of slot r is record vmap[r] of Vin (the records lag one reorder behind)
 // (The float32 instantiations are held to 64 registers, eight waves per SIMD instead of six: the kernel waits for the
 // potential, and more waves wait side by side -- 4 % on a uniform particle set, nothing spilled.)
-template <typename TP, typename TV, bool FUSED, bool SLAB, bool MAPPED>
+template <typename TP, typename TV, bool FUSED, bool SLAB, bool MAPPED, bool STREAM = false>
 __global__ void __launch_bounds__(BLOCK, (sizeof(TP) == 4 && sizeof(TV) == 4) ? 8 : 1)
 k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout, const pm_vrec<TV> *__restrict__ Vin,
          pm_vrec<TV> *__restrict__ Vout, const uint32_t *__restrict__ vmap,
@@ -1068,10 +1095,10 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
 #endif
     if (r >= n) return;
     const int G = g.G;
-    const pm_prec<TP> p = Pin[r];
+    const pm_prec<TP> p = stream_load<STREAM>(Pin + r);
     // the velocity record is asked for now -- its slot first, while the position is on its way -- and is there by the
     // time the forces are summed: two trips to memory in a row less than asking for it where it is used
-    pm_vrec<TV> v = Vin[MAPPED ? vmap[r] : r];
+    pm_vrec<TV> v = Vin[MAPPED ? stream_load<STREAM>(vmap + r) : r];
     cell_t c = locate(p, g);
     if constexpr (SLAB) {
         // A particle whose cell lies in another slab should not be here (pm_slab_inbox was handed a record that belongs
@@ -1165,7 +1192,7 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
     // velocities += forces*dt : the add runs in the velocities' dtype
     if constexpr (sizeof(TV) == 4) { v.x = v.x + dvx; v.y = v.y + dvy; v.z = v.z + dvz; }
     else { v.x = v.x + (double)dvx; v.y = v.y + (double)dvy; v.z = v.z + (double)dvz; }
-    Vout[r] = v;
+    stream_store<STREAM>(Vout + r, v);
     // positions += velocities*dt : float32 product for float32 velocities, the add in the wider
     // of the two dtypes, the result cast to float32 (on store, or by .astype at main.py:60)
     pm_prec<float> o;
@@ -1182,11 +1209,11 @@ k_gather(const pm_prec<TP> *__restrict__ Pin, pm_prec<float> *__restrict__ Pout,
         o.y = wrap_f32((float)((double)p.y + my), g.Lf);
         o.z = wrap_f32((float)((double)p.z + mz), g.Lf);
     }
-    Pout[r] = o;
+    stream_store<STREAM>(Pout + r, o);
     // cell key of the new position, for the next step's binning
     const cell_t cn = locate(o, g);
     const uint32_t kn = cell_key(cn, g);
-    key_next[r] = kn;
+    stream_store<STREAM>(key_next + r, kn);
     {
         // Which particles changed their cell: a bit per slot for the next binning, which may start from this order.
         // And how many, from a sample of the workgroups (full ones only), for the host to choose that binning by: one counter
@@ -1362,8 +1389,9 @@ hipError_t pm_launch_reorder(pm_ctx *c, bool row_starts)
     const uint32_t rs_blocks = row_starts ? (uint32_t)grid_for((int64_t)R + 1).x : 0u;
     dim3 grid = grid_for(n);
     grid.x += rs_blocks;
-    if (c->pos_f64) k_reorder<double><<<grid, BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g, c->key_out, R, c->row_start, rs_blocks);
-    else k_reorder<float><<<grid, BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g, c->key_out, R, c->row_start, rs_blocks);
+    if (c->pos_f64) k_reorder<double, false><<<grid, BLOCK, 0, c->stream>>>(c->pd[u], c->pd[w], c->frac, c->src, n, c->g, c->key_out, R, c->row_start, rs_blocks);
+    else if (n > PM_STREAM_MIN) k_reorder<float, true><<<grid, BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g, c->key_out, R, c->row_start, rs_blocks);
+    else k_reorder<float, false><<<grid, BLOCK, 0, c->stream>>>(c->pf[u], c->pf[w], c->frac, c->src, n, c->g, c->key_out, R, c->row_start, rs_blocks);
     c->cur = w;
     c->v_stale = true;
     return hipGetLastError();
@@ -1554,12 +1582,23 @@ static void gather_dispatch(pm_ctx *c, const pm_prec<TP> *P, pm_vrec<TV> *const 
         if (c->slab) {
             if constexpr (sizeof(TP) == 4 && sizeof(TV) == 4) {
                 const outbox_t ob{c->outbox, c->outbox_key, c->outbox_count, (uint32_t)c->outbox_cap, c->cuts, c->nslabs};
-                k_gather<float, float, true, true, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces,
-                                                                                           c->key_in, n, c->g, dt, integrate, ob, probe);
+                if (n > PM_STREAM_MIN)
+                    k_gather<float, float, true, true, M, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential,
+                                                                                                     forces, c->key_in, n, c->g, dt, integrate, ob, probe);
+                else
+                    k_gather<float, float, true, true, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces,
+                                                                                               c->key_in, n, c->g, dt, integrate, ob, probe);
             }
-        } else if (fused)
+        } else if (fused) {
+            // (the float32 step of a set too large for the caches: the records in and out marked as streaming)
+            if constexpr (sizeof(TP) == 4 && sizeof(TV) == 4) {
+                if (n > PM_STREAM_MIN) {
+                    k_gather<TP, TV, true, false, M, true><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate, outbox_t{}, probe);
+                    return;
+                }
+            }
             k_gather<TP, TV, true, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, nullptr, nullptr, nullptr, c->potential, forces, c->key_in, n, c->g, dt, integrate, outbox_t{}, probe);
-        else
+        } else
             k_gather<TP, TV, false, false, M><<<grid_for(n), BLOCK, 0, c->stream>>>(P, out, vin, vout, vmap, c->grad[0], c->grad[1], c->grad[2], nullptr, forces, c->key_in, n, c->g, dt, integrate, outbox_t{}, probe);
     };
     if (vmap) launch(std::true_type{});

@@ -314,7 +314,7 @@ constexpr uint32_t LOOK = PM_SORT_LOOK;             // states of earlier tiles r
 // CHAINED = false: tile b is workgroup b's, `digit_base` holds the pairs with each digit in all tiles (k_scan_tiles'
 // digit_total) and `states` is the scanned table of tile counts, of which the workgroup reads row b: no ticket, no
 // look-back, nothing is published.
-template <typename K, typename S, unsigned RADIX, bool COUNTED, bool ON_DEVICE, bool CHAINED, class Sink>
+template <typename K, typename S, unsigned RADIX, bool COUNTED, bool ON_DEVICE, bool CHAINED, class Sink, bool STREAM = false>
 __global__ void __launch_bounds__(SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(PM_PASS_WAVES)))
 k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t n, const uint32_t *__restrict__ digit_base,
              S *__restrict__ states, uint32_t *__restrict__ ticket, unsigned bit, uint32_t mask, Sink sink, const uint32_t *__restrict__ n_dev)
@@ -365,9 +365,15 @@ k_radix_pass(const K *__restrict__ kin, const uint32_t *__restrict__ vin, uint32
     for (int i = 0; i < SORT_ITEMS; ++i) {
         const uint32_t q = first + 64u * i;
         const bool live = q < count;
-        key[i] = live ? ktile[q] : (K)0;
-        // COUNTED: the values that go in are the storage indices 0, 1, 2, ... -- nothing to read
-        val[i] = COUNTED ? base + q : (live ? vtile[q] : 0u);
+        // (STREAM: a pass is the last reader of its input -- non-temporal loads, in sorts too large for the caches to matter)
+        if constexpr (STREAM) {
+            key[i] = live ? __builtin_nontemporal_load(ktile + q) : (K)0;
+            val[i] = COUNTED ? base + q : (live ? __builtin_nontemporal_load(vtile + q) : 0u);
+        } else {
+            key[i] = live ? ktile[q] : (K)0;
+            // COUNTED: the values that go in are the storage indices 0, 1, 2, ... -- nothing to read
+            val[i] = COUNTED ? base + q : (live ? vtile[q] : 0u);
+        }
     }
 
     // Rank of every pair among the pairs of its wave with the same digit.  The lanes whose digits agree find each
@@ -559,18 +565,20 @@ hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, si
                        unsigned now, Sink sink, int device, hipStream_t s, pm_ctx *timed, const uint32_t *n_dev, bool chained)
 {
     constexpr size_t lds = pass_lds_bytes<K, RADIX>();
-    auto allow = [&](const void *kernel) -> hipError_t {
+    auto allow_slot = [&](const void *kernel, int slot) -> hipError_t {
         if (lds <= 64 * 1024) return hipSuccess;
         // more LDS than a kernel gets by default: allowed once per kernel and device (a bit per device; setting it
         // twice from two threads is harmless)
-        static std::atomic<uint64_t> allowed[3] = {};
-        std::atomic<uint64_t> &a = allowed[n_dev ? 1 : chained ? 0 : 2];
+        static std::atomic<uint64_t> allowed[4] = {};
+        std::atomic<uint64_t> &a = allowed[slot];
         const uint64_t bit_of = 1ull << (device & 63);
         if (a.load(std::memory_order_acquire) & bit_of) return hipSuccess;
         hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) a.fetch_or(bit_of, std::memory_order_release);
         return e;
     };
+    auto allow = [&](const void *kernel) { return allow_slot(kernel, n_dev ? 1 : chained ? 0 : 2); };
+    auto allow_streaming = [&](const void *kernel) { return allow_slot(kernel, 3); };
     pm_timer timer(timed, PM_NSTAGES + PM_KERNEL_SORT_PASS);
     if (n_dev) {
         auto kernel = k_radix_pass<K, S, RADIX, COUNTED, true, true, Sink>;
@@ -584,6 +592,14 @@ hipError_t launch_pass(const sort_plan &p, const K *kin, const uint32_t *vin, si
         if (e != hipSuccess) return e;
         kernel<<<p.tiles, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink, n_dev);
     } else {
+        // (a sort of more than 4M pairs of 4-byte keys reads its input as streaming data)
+        if (sizeof(K) == 4 && n > ((size_t)1 << 22)) {
+            auto kernel = k_radix_pass<K, S, RADIX, COUNTED, false, false, Sink, true>;
+            hipError_t e = allow_streaming((const void *)kernel);
+            if (e != hipSuccess) return e;
+            kernel<<<p.tiles, SORT_BLOCK, lds, s>>>(kin, vin, (uint32_t)n, digit_base, (S *)states, ticket, bit, (1u << now) - 1u, sink, n_dev);
+            return hipGetLastError();
+        }
         auto kernel = k_radix_pass<K, S, RADIX, COUNTED, false, false, Sink>;
         hipError_t e = allow((const void *)kernel);
         if (e != hipSuccess) return e;
